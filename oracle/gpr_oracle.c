@@ -1,0 +1,771 @@
+/*
+ * gpr_oracle.c -- CPU ORACLE (test infrastructure, NOT product code). See gpr_oracle.h for scope and parity status.
+ *
+ * Written to follow the reference's NumPy code operation by operation (same comparisons, same inclusive /
+ * strict inequalities, same evaluation order for floating point), NOT to be fast. Build with
+ * -ffp-contract=off so that no a*b+c is fused except where fma() is written out.
+ *
+ * BE = gymnasium_planar_robotics/envs/basic_envs.py, PL = envs/planning/benchmark_planning_env.py,
+ * GEO = utils/geometry_2D_utils.py, ROT = utils/rotations_utils.py (all under /root/reference).
+ */
+#include "gpr_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXT 64 /* max tiles per axis handled by the oracle */
+
+static void track(double *margin, double lhs, double rhs) {
+    if (margin) {
+        double d = fabs(lhs - rhs);
+        if (d < *margin) *margin = d;
+    }
+}
+
+/* ======================================================================================================
+ * ctor-time tables
+ * ==================================================================================================== */
+
+/* numpy.linspace(start, stop, num, endpoint=True) (numpy/_core/function_base.py, published algorithm):
+ *   step = (stop-start)/(num-1); y = arange(num)*step + start; y[-1] = stop.
+ * Called as in get_tile_xy_pos / get_1D_tile_pos (BE:1300-1302) with tile_wl = tile_size*2. */
+void gpro_tile_centres(int32_t n, double tile_half_size, double *out) {
+    double tile_wl = tile_half_size * 2;
+    double start = tile_wl / 2;
+    double stop = (n - 1) * tile_wl + (tile_wl / 2);
+    int32_t div = n - 1;
+    double delta = stop - start;
+    for (int32_t i = 0; i < n; ++i) {
+        double y = (double)i;
+        if (div > 0) {
+            double step = delta / div;
+            if (step == 0.0) {
+                y = y / div;
+                y = y * delta;
+            } else {
+                y = y * step;
+            }
+        } else {
+            y = y * delta;
+        }
+        out[i] = y + start;
+    }
+    if (n > 1) out[n - 1] = stop;
+}
+
+static int lay_at(const gpro_layout *lay, int ix, int iy) {
+    /* layout_tiles_wc (BE:221) is the layout padded by one zero row / column at the END; Python's negative index -1
+     * therefore also lands on the zero padding. Out-of-range == 0. */
+    if (ix < 0 || iy < 0 || ix >= lay->num_tiles_x || iy >= lay->num_tiles_y) return 0;
+    return lay->layout[ix * lay->num_tiles_y + iy];
+}
+
+/* get_tile_indices_mask (BE:1312-1339). */
+int32_t gpro_tile_indices_mask(const gpro_layout *lay, int32_t which, int32_t cap, int32_t *out_ix, int32_t *out_iy) {
+    static const int8_t m3[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static const int8_t mbl[4] = {1, 1, 0, 1}; /* BE:209 */
+    static const int8_t mbr[4] = {1, 1, 1, 0}; /* BE:212 */
+    static const int8_t mtl[4] = {0, 1, 1, 1}; /* BE:215 */
+    static const int8_t mtr[4] = {1, 0, 1, 1}; /* BE:218 */
+    const int8_t *mask = which == 0 ? m3 : which == 1 ? mbl : which == 2 ? mbr : which == 3 ? mtl : mtr;
+    int ms = which == 0 ? 3 : 2;
+    /* offsets (BE:1322-1323): odd size -> (s/2, s/2-1); even size -> (s/2-1, s/2-1) */
+    int off0 = (ms % 2 == 1) ? ms / 2 : ms / 2 - 1;
+    int off1 = ms / 2 - 1;
+    int32_t cnt = 0;
+    for (int ix = off0; ix < lay->num_tiles_x - off1 - 1; ++ix) {
+        for (int iy = off0; iy < lay->num_tiles_y - off1 - 1; ++iy) {
+            int ok = 1;
+            /* slice [ix-off0 : ix+off1+2] has ms entries when in range (it always is for these loop bounds) */
+            for (int a = 0; a < ms && ok; ++a)
+                for (int b = 0; b < ms && ok; ++b)
+                    if (mask[a * ms + b] != lay->layout[(ix - off0 + a) * lay->num_tiles_y + (iy - off0 + b)]) ok = 0;
+            if (ok) {
+                if (cnt < cap) {
+                    out_ix[cnt] = ix;
+                    out_iy[cnt] = iy;
+                }
+                ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
+/* PL:242-245 (goal space high), PL:262-267 (min/max xy), PL:270-274 (min_goal_dist). */
+void gpro_planning_constants(const gpro_layout *lay, const double *c_size, double *min_xy, double *max_xy,
+                             double *min_goal_dist, double *goal_high) {
+    double xc[MAXT], yc[MAXT];
+    gpro_tile_centres(lay->num_tiles_x, lay->tile_hx, xc);
+    gpro_tile_centres(lay->num_tiles_y, lay->tile_hy, yc);
+    double mx = xc[0], my = yc[0];
+    for (int i = 1; i < lay->num_tiles_x; ++i) if (xc[i] > mx) mx = xc[i];
+    for (int i = 1; i < lay->num_tiles_y; ++i) if (yc[i] > my) my = yc[i];
+    double hi[2] = {mx + (lay->tile_hx / 2), my + (lay->tile_hy / 2)}; /* tile_size is already a half size: quirk kept */
+    for (int d = 0; d < 2; ++d) {
+        double cs = lay->c_shape == 0 ? c_size[0] : c_size[d];
+        double safety_margin = cs + lay->c_offset_wall + lay->c_offset;
+        min_xy[d] = 0.0 + safety_margin;
+        max_xy[d] = hi[d] - safety_margin;
+        goal_high[d] = hi[d];
+    }
+    if (lay->c_shape == 0) {
+        *min_goal_dist = 2 * (c_size[0] + lay->c_offset);
+    } else {
+        double a = c_size[0] + lay->c_offset, b = c_size[1] + lay->c_offset;
+        *min_goal_dist = 2 * sqrt(a * a + b * b);
+    }
+}
+
+/* ======================================================================================================
+ * geometry_2D_utils
+ * ==================================================================================================== */
+
+/* det of [[ax,bx,cx],[ay,by,cy],[1,1,1]] (GEO:47-60 build exactly this matrix; numpy.linalg.det is LAPACK LU, whose
+ * result equals this cofactor expansion up to rounding; the reference only uses sign(d1*d2) and |d1*d2| < 1e-7). */
+static double det3(double ax, double ay, double bx, double by, double cx, double cy) {
+    return ax * (by - cy) - bx * (ay - cy) + cx * (ay - by);
+}
+
+static int seg_intersect(const double *p1, const double *p2, const double *q1, const double *q2) {
+    /* GEO:30-35 */
+    int eq = 0;
+    eq |= (fabs(p1[0] - q1[0]) < 1e-7) + (fabs(p1[1] - q1[1]) < 1e-7) == 2;
+    eq |= (fabs(p1[0] - q2[0]) < 1e-7) + (fabs(p1[1] - q2[1]) < 1e-7) == 2;
+    eq |= (fabs(p2[0] - q1[0]) < 1e-7) + (fabs(p2[1] - q1[1]) < 1e-7) == 2;
+    eq |= (fabs(p2[0] - q2[0]) < 1e-7) + (fabs(p2[1] - q2[1]) < 1e-7) == 2;
+    /* GEO:37-45 */
+    int minmax = 0;
+    for (int d = 0; d < 2; ++d) {
+        double min_p = fmin(p1[d], p2[d]), max_p = fmax(p1[d], p2[d]);
+        double min_q = fmin(q1[d], q2[d]), max_q = fmax(q1[d], q2[d]);
+        int mask_pq = max_p < min_q, mask_qp = max_q < min_p;
+        minmax += mask_pq * (1 - (fabs(max_p - min_q) < 1e-7)) + mask_qp * (1 - (fabs(max_q - min_p) < 1e-7));
+    }
+    /* GEO:47-64 */
+    double d_ppq1 = det3(p1[0], p1[1], p2[0], p2[1], q1[0], q1[1]);
+    double d_ppq2 = det3(p1[0], p1[1], p2[0], p2[1], q2[0], q2[1]);
+    double d_qqp1 = det3(q1[0], q1[1], q2[0], q2[1], p1[0], p1[1]);
+    double d_qqp2 = det3(q1[0], q1[1], q2[0], q2[1], p2[0], p2[1]);
+    double pp = d_ppq1 * d_ppq2, qq = d_qqp1 * d_qqp2;
+    /* np.sign(x) <= 0  <=>  x <= 0 (NaN excluded) */
+    int orient = ((pp <= 0) || (fabs(pp) < 1e-7)) && ((qq <= 0) || (fabs(qq) < 1e-7));
+    /* GEO:66-68: order matters */
+    int res = 0;
+    if (orient) res = 1;
+    if (minmax >= 1) res = 0;
+    if (eq) res = 1;
+    return res;
+}
+
+void gpro_check_line_segments_intersect(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2,
+                                        uint8_t *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)seg_intersect(p1 + 2 * i, p2 + 2 * i, q1 + 2 * i, q2 + 2 * i);
+}
+
+/* GEO:72-104 with ROT:414-461 (unit_vector: float32!) and ROT:248-274 (quat2mat). vx/vy: 4 vertices in the order
+ * (-,-), (-,+), (+,+), (+,-) (GEO:91-97). */
+static void rect_vertices(const double *qpos, double sx, double sy, double *vx, double *vy) {
+    /* unit_vector(quats, axis=1): data = np.array(data, dtype=np.float32); length = sqrt(sum(data*data)); data /= length */
+    float qf[4];
+    for (int i = 0; i < 4; ++i) qf[i] = (float)qpos[3 + i];
+    float len = ((qf[0] * qf[0] + qf[1] * qf[1]) + qf[2] * qf[2]) + qf[3] * qf[3];
+    len = sqrtf(len);
+    for (int i = 0; i < 4; ++i) qf[i] = qf[i] / len;
+    /* quat2mat in float64 */
+    double w = qf[0], x = qf[1], y = qf[2], z = qf[3];
+    double Nq = ((w * w + x * x) + y * y) + z * z;
+    double s = 2.0 / Nq;
+    double X = x * s, Y = y * s, Z = z * s;
+    double wZ = w * Z;
+    double xX = x * X, xY = x * Y;
+    double yY = y * Y, zZ = z * Z;
+    double R00 = 1.0 - (yY + zZ), R01 = xY - wZ;
+    double R10 = xY + wZ, R11 = 1.0 - (xX + zZ);
+    if (!(Nq > DBL_EPSILON)) { /* ROT:274, _FLOAT_EPS = finfo(float64).eps */
+        R00 = 1.0; R01 = 0.0; R10 = 0.0; R11 = 1.0;
+    }
+    const double lx[4] = {-sx, -sx, sx, sx};
+    const double ly[4] = {-sy, sy, sy, -sy};
+    for (int j = 0; j < 4; ++j) {
+        /* rot_mats @ vertices_l (GEO:102). vertices_l is a swapaxes view, so for more than one rectangle NumPy's matmul
+         * takes its own (non-BLAS) loop: out = 0; out += R[i,k]*v[k] for k = 0,1,2, unfused. (For a batch of exactly ONE
+         * rectangle the view is contiguous and the product goes to BLAS, whose FMA chain can differ in the last bit: the
+         * reference's vertices depend on batch size at the 1-ulp level. The batched form is the canonical one here;
+         * verified bit-for-bit against the 6000-rectangle fixture.) The z term is R[i,2]*0 = 0. */
+        double rx = R00 * lx[j] + R01 * ly[j];
+        double ry = R10 * lx[j] + R11 * ly[j];
+        vx[j] = rx + qpos[0];
+        vy[j] = ry + qpos[1];
+    }
+}
+
+void gpro_get_2D_rect_vertices(int64_t n, const double *qpos, const double *size, double *out) {
+    for (int64_t i = 0; i < n; ++i)
+        rect_vertices(qpos + 7 * i, size[2 * i], size[2 * i + 1], out + 8 * i, out + 8 * i + 4);
+}
+
+/* GEO:107-138: 4 x 4 edge pairs, edge k = vertex k -> vertex (k+1)%4 (np.roll(shift=-1)). */
+static int rects_intersect(const double *qpos1, const double *qpos2, double s1x, double s1y, double s2x, double s2y) {
+    double ax[4], ay[4], bx[4], by[4];
+    rect_vertices(qpos1, s1x, s1y, ax, ay);
+    rect_vertices(qpos2, s2x, s2y, bx, by);
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            double p1[2] = {ax[i], ay[i]}, p2[2] = {ax[(i + 1) & 3], ay[(i + 1) & 3]};
+            double q1[2] = {bx[j], by[j]}, q2[2] = {bx[(j + 1) & 3], by[(j + 1) & 3]};
+            cnt += seg_intersect(p1, p2, q1, q2);
+        }
+    }
+    return cnt >= 1;
+}
+
+void gpro_check_rectangles_intersect(int64_t n, const double *qpos_r1, const double *qpos_r2, const double *size_r1,
+                                     const double *size_r2, uint8_t *out) {
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = (uint8_t)rects_intersect(qpos_r1 + 7 * i, qpos_r2 + 7 * i, size_r1[2 * i], size_r1[2 * i + 1], size_r2[2 * i],
+                                          size_r2[2 * i + 1]);
+}
+
+/* ======================================================================================================
+ * qpos_is_valid (BE:459-788)
+ * ==================================================================================================== */
+
+static int is_3x3_centre(const gpro_layout *lay, int ix, int iy) {
+    /* membership in idx_x/y_tiles_3x3 (BE:206-207 via BE:1312-1339) */
+    if (ix < 1 || iy < 1 || ix > lay->num_tiles_x - 2 || iy > lay->num_tiles_y - 2) return 0;
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b)
+            if (lay->layout[(ix + a) * lay->num_tiles_y + (iy + b)] != 1) return 0;
+    return 1;
+}
+
+/* does the 2x2 block with top-left (bx,by) equal the mask (m00 m01; m10 m11)?  (rows = x index, cols = y index) */
+static int block_is(const gpro_layout *lay, int bx, int by, int m00, int m01, int m10, int m11) {
+    if (bx < 0 || by < 0 || bx > lay->num_tiles_x - 2 || by > lay->num_tiles_y - 2) return 0;
+    const int8_t *L = lay->layout;
+    int ty = lay->num_tiles_y;
+    return L[bx * ty + by] == m00 && L[bx * ty + by + 1] == m01 && L[(bx + 1) * ty + by] == m10 && L[(bx + 1) * ty + by + 1] == m11;
+}
+
+/* one qpos; cs0/cs1 already include offset_wall (+ offset). Returns validity; *above = number of tiles it is over. */
+static int qpos_valid_one(const gpro_layout *lay, const double *xc, const double *yc, const double *qpos, double cs0, double cs1,
+                          int *above_cnt, double *margin) {
+    const int circle = lay->c_shape == 0;
+    const int Tx = lay->num_tiles_x, Ty = lay->num_tiles_y;
+    const double hx = lay->tile_hx, hy = lay->tile_hy;
+    double vx[4], vy[4];
+    if (!circle) rect_vertices(qpos, cs0, cs1, vx, vy); /* BE:496-497 */
+    int any = 0, valid3 = 0, all_k = 1;
+    for (int ix = 0; ix < Tx; ++ix) {
+        for (int iy = 0; iy < Ty; ++iy) {
+            double cx = xc[ix], cy = yc[iy];
+            /* BE:508-513, inclusive, independent of whether the tile exists */
+            int above = (cx - hx <= qpos[0]) && (qpos[0] <= cx + hx) && (cy - hy <= qpos[1]) && (qpos[1] <= cy + hy);
+            track(margin, cx - hx, qpos[0]); track(margin, qpos[0], cx + hx);
+            track(margin, cy - hy, qpos[1]); track(margin, qpos[1], cy + hy);
+            if (!above) continue;
+            any += 1;
+            if (is_3x3_centre(lay, ix, iy)) valid3 = 1; /* BE:530-538 */
+            double min_x = cx - hx, max_x = cx + hx, min_y = cy - hy, max_y = cy + hy; /* BE:522-526 */
+            int L = lay_at(lay, ix, iy);
+            int rep = circle ? 1 : 4;
+            int sum_valid = 0;
+            int lmin_x = ix > 0, lmin_y = iy > 0, smax_x = ix < Tx - 1, smax_y = iy < Ty - 1; /* BE:575-578 */
+            for (int r = 0; r < rep; ++r) {
+                int mnx, mxx, mny, mxy;
+                if (circle) { /* BE:545-558 */
+                    double xm = qpos[0] - cs0, xp = qpos[0] + cs0, ym = qpos[1] - cs0, yp = qpos[1] + cs0;
+                    mnx = L * (min_x < xm); mxx = L * (xp < max_x); mny = L * (min_y < ym); mxy = L * (yp < max_y);
+                    track(margin, min_x, xm); track(margin, xp, max_x); track(margin, min_y, ym); track(margin, yp, max_y);
+                } else { /* BE:560-572 */
+                    mnx = L * (min_x < vx[r]); mxx = L * (vx[r] < max_x); mny = L * (min_y < vy[r]); mxy = L * (vy[r] < max_y);
+                    track(margin, min_x, vx[r]); track(margin, vx[r], max_x); track(margin, min_y, vy[r]); track(margin, vy[r], max_y);
+                }
+                int mv = mnx * mxx * mny * mxy; /* BE:580 */
+                /* BE:582-607 */
+                int upd_mnx = (1 - mnx) * (lmin_x * lay_at(lay, ix, iy) * lay_at(lay, ix - 1, iy));
+                mv += upd_mnx * mny * mxy;
+                int upd_mnx_mny = (1 - mny) * (lmin_x * lmin_y * lay_at(lay, ix, iy) * lay_at(lay, ix, iy - 1) * lay_at(lay, ix - 1, iy - 1));
+                mv += upd_mnx * upd_mnx_mny;
+                int upd_mnx_mxy = (1 - mxy) * (lmin_x * smax_y * lay_at(lay, ix, iy) * lay_at(lay, ix, iy + 1) * lay_at(lay, ix - 1, iy + 1));
+                mv += upd_mnx * upd_mnx_mxy;
+                /* BE:609-634 */
+                int upd_mxx = (1 - mxx) * (smax_x * lay_at(lay, ix, iy) * lay_at(lay, ix + 1, iy));
+                mv += upd_mxx * mny * mxy;
+                int upd_mxx_mny = (1 - mny) * (smax_x * lmin_y * lay_at(lay, ix, iy) * lay_at(lay, ix, iy - 1) * lay_at(lay, ix + 1, iy - 1));
+                mv += upd_mxx * upd_mxx_mny;
+                int upd_mxx_mxy = (1 - mxy) * (smax_x * smax_y * lay_at(lay, ix, iy) * lay_at(lay, ix, iy + 1) * lay_at(lay, ix + 1, iy + 1));
+                mv += upd_mxx * upd_mxx_mxy;
+                /* BE:636-648 */
+                int upd_mny = (1 - mny) * (lmin_y * lay_at(lay, ix, iy) * lay_at(lay, ix, iy - 1));
+                mv += upd_mny * mnx * mxx;
+                int upd_mxy = (1 - mxy) * (smax_y * lay_at(lay, ix, iy) * lay_at(lay, ix, iy + 1));
+                mv += upd_mxy * mnx * mxx;
+                sum_valid += mv;
+            }
+            int valid_k;
+            if (circle) {
+                valid_k = (sum_valid == 1); /* BE:653 + BE:785 (== 1) */
+            } else {
+                valid_k = (sum_valid == 4); /* BE:655 */
+                /* BE:657-783: L-shaped 2x2 neighbourhoods, rectangle test against the missing (diagonal) tile */
+                struct { int ok_range; int bx, by, m00, m01, m10, m11, mx, my; } c4[4] = {
+                    /* bottom left  BE:658-687: entry == (bl_x, bl_y+1); missing (bl_x+1, bl_y) */
+                    {smax_x && lmin_y, ix, iy - 1, 1, 1, 0, 1, ix + 1, iy - 1},
+                    /* bottom right BE:690-719: entry == (br_x, br_y); missing (br_x+1, br_y+1) */
+                    {smax_x && smax_y, ix, iy, 1, 1, 1, 0, ix + 1, iy + 1},
+                    /* top left     BE:722-751: entry == (tl_x+1, tl_y+1); missing (tl_x, tl_y) */
+                    {lmin_x && lmin_y, ix - 1, iy - 1, 0, 1, 1, 1, ix - 1, iy - 1},
+                    /* top right    BE:754-783: entry == (tr_x+1, tr_y); missing (tr_x, tr_y+1) */
+                    {lmin_x && smax_y, ix - 1, iy, 1, 0, 1, 1, ix - 1, iy + 1},
+                };
+                for (int c = 0; c < 4; ++c) {
+                    if (!(valid_k && c4[c].ok_range)) continue;
+                    if (!block_is(lay, c4[c].bx, c4[c].by, c4[c].m00, c4[c].m01, c4[c].m10, c4[c].m11)) continue;
+                    double qm[7] = {xc[c4[c].mx], yc[c4[c].my], 0, 1, 0, 0, 0};
+                    int inter = rects_intersect(qpos, qm, cs0, cs1, hx, hy);
+                    valid_k = (1 - inter) * valid_k;
+                }
+            }
+            if (!valid_k) all_k = 0;
+        }
+    }
+    *above_cnt = any;
+    /* BE:538 (3x3 positions stay valid) and BE:785-786 */
+    return valid3 || (any > 0 && all_k);
+}
+
+int64_t gpro_qpos_is_valid(const gpro_layout *lay, int64_t n, const double *qpos, const double *c_size, int32_t add_safety_offset,
+                           int32_t *out, double *margin) {
+    double xc[MAXT], yc[MAXT];
+    gpro_tile_centres(lay->num_tiles_x, lay->tile_hx, xc);
+    gpro_tile_centres(lay->num_tiles_y, lay->tile_hy, yc);
+    int64_t n_off = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        /* BE:487: c_size + offset_wall + int(add)*offset, left to right */
+        double cs0 = c_size[2 * i] + lay->c_offset_wall + (double)(add_safety_offset != 0) * lay->c_offset;
+        double cs1 = c_size[2 * i + 1] + lay->c_offset_wall + (double)(add_safety_offset != 0) * lay->c_offset;
+        int above = 0;
+        double m = INFINITY;
+        out[i] = qpos_valid_one(lay, xc, yc, qpos + 7 * i, cs0, cs1, &above, margin ? &m : NULL);
+        if (margin) margin[i] = m;
+        if (above == 0) ++n_off;
+    }
+    return n_off;
+}
+
+/* ======================================================================================================
+ * check_mover_collision (BE:355-424)
+ * ==================================================================================================== */
+int32_t gpro_check_mover_collision(const gpro_layout *lay, int32_t m, const double *qpos, const double *c_size,
+                                   int32_t add_safety_offset, double *margin) {
+    double cs[GPRO_MAX_MOVERS * 2];
+    for (int i = 0; i < m; ++i) { /* BE:390 */
+        cs[2 * i] = c_size[2 * i] + lay->c_offset * (double)(add_safety_offset != 0);
+        cs[2 * i + 1] = c_size[2 * i + 1] + lay->c_offset * (double)(add_safety_offset != 0);
+    }
+    int coll = 0;
+    if (lay->c_shape == 0) {
+        /* BE:409: norm has shape (K,), (c_i + c_j) has shape (K,1): NumPy broadcasts the comparison to (K,K), i.e.
+         * collision = any_{a,b} norm[b] <= csum[a]. Identical to the per-pair test when all radii are equal. */
+        for (int ia = 0; ia < m - 1; ++ia) for (int ja = ia + 1; ja < m; ++ja) {
+            double csum = cs[2 * ia] + cs[2 * ja];
+            for (int ib = 0; ib < m - 1; ++ib) for (int jb = ib + 1; jb < m; ++jb) {
+                double dx = qpos[7 * ib] - qpos[7 * jb], dy = qpos[7 * ib + 1] - qpos[7 * jb + 1];
+                double norm = sqrt(dx * dx + dy * dy);
+                track(margin, norm, csum);
+                if (norm <= csum) coll = 1;
+            }
+        }
+    } else {
+        for (int i = 0; i < m - 1; ++i) for (int j = i + 1; j < m; ++j) {
+            double dx = qpos[7 * i] - qpos[7 * j], dy = qpos[7 * i + 1] - qpos[7 * j + 1];
+            double dist = sqrt(dx * dx + dy * dy);
+            double ms = fmax(fmax(cs[2 * i], cs[2 * i + 1]), fmax(cs[2 * j], cs[2 * j + 1])); /* BE:412 */
+            double lim = 2 * (fabs(ms) + fabs(ms));                                            /* BE:413-414, ord=1 */
+            track(margin, dist, lim);
+            if (dist <= lim) {
+                if (rects_intersect(qpos + 7 * i, qpos + 7 * j, cs[2 * i], cs[2 * i + 1], cs[2 * j], cs[2 * j + 1])) coll = 1;
+            }
+        }
+    }
+    return coll;
+}
+
+/* ======================================================================================================
+ * dynamics helpers
+ * ==================================================================================================== */
+
+/* PL:610-645, one row. Returns 1 if the clamp branch was taken. */
+static int clamp_one(const double *cur, double max_value, const double *deriv, double dt, double *vals, double *ders, double *margin) {
+    double t0 = dt * deriv[0] + cur[0], t1 = dt * deriv[1] + cur[1]; /* PL:631 */
+    double norm = sqrt(t0 * t0 + t1 * t1);                           /* PL:633 */
+    track(margin, norm, max_value);
+    if (norm >= max_value) { /* PL:634 inclusive */
+        vals[0] = max_value * (t0 / norm); /* PL:640-642 */
+        vals[1] = max_value * (t1 / norm);
+        ders[0] = (vals[0] - cur[0]) / dt; /* PL:643 */
+        ders[1] = (vals[1] - cur[1]) / dt;
+        return 1;
+    }
+    vals[0] = t0; vals[1] = t1; ders[0] = deriv[0]; ders[1] = deriv[1];
+    return 0;
+}
+
+void gpro_ensure_max_dyn_val(int64_t n, const double *cur, const double *max_value, const double *deriv, double dt, double *out_vals,
+                             double *out_derivs) {
+    for (int64_t i = 0; i < n; ++i) clamp_one(cur + 2 * i, max_value[i], deriv + 2 * i, dt, out_vals + 2 * i, out_derivs + 2 * i, NULL);
+}
+
+static void reward_one(int32_t M, const double *ag, const double *dg, int mc, int wc, double thr, double rs, double *reward,
+                       uint8_t *terminated, uint8_t *is_success, double *margin) {
+    int n_reached = 0;
+    for (int i = 0; i < M; ++i) { /* PL:647-664, PL:524 */
+        double dx = ag[2 * i] - dg[2 * i], dy = ag[2 * i + 1] - dg[2 * i + 1];
+        double dist = sqrt(dx * dx + dy * dy);
+        track(margin, dist, thr);
+        n_reached += dist <= thr;
+    }
+    int coll = mc || wc;
+    double r = -rs * (double)coll;                       /* PL:529 */
+    r += -1.0 * (double)(M - n_reached) * (double)(!coll); /* PL:530 */
+    if (n_reached == M && !coll) r = rs;                  /* PL:531 */
+    *reward = r;
+    *terminated = (r == rs) || (r == -rs);                /* PL:478 */
+    *is_success = (n_reached == M) && !mc && !wc;         /* PL:597 */
+}
+
+void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achieved, const double *desired, const uint8_t *mover_collision,
+                         const uint8_t *wall_collision, double threshold_pos, double reward_success, double *reward, uint8_t *terminated,
+                         uint8_t *is_success) {
+    for (int64_t b = 0; b < batch; ++b)
+        reward_one(num_movers, achieved + 2 * num_movers * b, desired + 2 * num_movers * b, mover_collision[b], wall_collision[b],
+                   threshold_pos, reward_success, reward + b, terminated + b, is_success + b, NULL);
+}
+
+/* ======================================================================================================
+ * Engine RNG spec "gpr-rng-v1" (engine-defined). 32-bit ops only so the HIP kernels can run the same
+ * integer sequence: key -> lowbias32 absorb chain -> xoshiro128++ state; Box-Muller on 24-bit uniforms.
+ * ==================================================================================================== */
+static uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+void gpro_rng_seed(gpro_rng *r, uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t stream) {
+    uint32_t h = 0x9E3779B9U;
+    h = mix32(h ^ (uint32_t)seed);
+    h = mix32(h ^ (uint32_t)(seed >> 32));
+    h = mix32(h ^ (uint32_t)tick);
+    h = mix32(h ^ (uint32_t)(tick >> 32));
+    h = mix32(h ^ stream);
+    h = mix32(h ^ (uint32_t)env_id);
+    h = mix32(h ^ (uint32_t)(env_id >> 32));
+    for (int i = 0; i < 4; ++i) r->s[i] = mix32(h + (uint32_t)(i + 1) * 0x9E3779B9U);
+    if ((r->s[0] | r->s[1] | r->s[2] | r->s[3]) == 0) r->s[0] = 1;
+}
+
+uint32_t gpro_rng_next(gpro_rng *r) { /* xoshiro128++ (Blackman & Vigna) */
+    uint32_t *s = r->s;
+    uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+    uint32_t t = s[1] << 9;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl32(s[3], 11);
+    return result;
+}
+
+double gpro_rng_uniform(gpro_rng *r) { return (double)(gpro_rng_next(r) >> 8) * (1.0 / 16777216.0); } /* [0,1) */
+
+void gpro_rng_normal_pair(gpro_rng *r, double *n0, double *n1) {
+    uint32_t a = gpro_rng_next(r), b = gpro_rng_next(r);
+    double u1 = (double)((a >> 8) + 1) * (1.0 / 16777216.0); /* (0,1] */
+    double u2 = (double)(b >> 8) * (1.0 / 16777216.0);       /* [0,1) */
+    double rad = sqrt(-2.0 * log(u1));
+    double ang = 6.283185307179586476925286766559 * u2;
+    *n0 = rad * cos(ang);
+    *n1 = rad * sin(ang);
+}
+
+/* ======================================================================================================
+ * Vectorised BenchmarkPlanningEnv (BE:1770-1950 template + PL callbacks), one env at a time.
+ * ==================================================================================================== */
+typedef struct {
+    const gpro_env_cfg *cfg;
+    double xc[MAXT], yc[MAXT];
+    int noise;
+} env_ctx;
+
+static double q32(const gpro_env_cfg *cfg, double x) { return cfg->storage_f32 ? (double)(float)x : x; }
+
+static void make_qpos(int M, const double *xy, double *qpos) {
+    for (int i = 0; i < M; ++i) {
+        double *q = qpos + 7 * i;
+        q[0] = xy[2 * i]; q[1] = xy[2 * i + 1]; q[2] = 0.0; q[3] = 1.0; q[4] = q[5] = q[6] = 0.0;
+    }
+}
+
+/* noisy copy of M xy pairs: one Box-Muller pair per mover (x <- n0, y <- n1) */
+static void noisy(const env_ctx *c, gpro_rng *rng, int M, const double *xy, double sigma, double *out) {
+    for (int i = 0; i < M; ++i) {
+        double n0 = 0.0, n1 = 0.0;
+        if (c->noise) gpro_rng_normal_pair(rng, &n0, &n1);
+        out[2 * i] = xy[2 * i] + sigma * n0;
+        out[2 * i + 1] = xy[2 * i + 1] + sigma * n1;
+    }
+}
+
+/* check_wall_collision(...).any() (BE:426-457) on xy positions */
+static int wall_any(const env_ctx *c, const double *xy, int add_safety, double *margin) {
+    const gpro_env_cfg *cfg = c->cfg;
+    int M = cfg->num_movers, wall = 0;
+    for (int i = 0; i < M; ++i) {
+        double q[7] = {xy[2 * i], xy[2 * i + 1], 0, 1, 0, 0, 0};
+        double cs0 = cfg->c_size[2 * i] + cfg->lay.c_offset_wall + (double)(add_safety != 0) * cfg->lay.c_offset;
+        double cs1 = cfg->c_size[2 * i + 1] + cfg->lay.c_offset_wall + (double)(add_safety != 0) * cfg->lay.c_offset;
+        int above = 0;
+        int valid = qpos_valid_one(&cfg->lay, c->xc, c->yc, q, cs0, cs1, &above, margin);
+        if (!valid) wall = 1; /* a mover above no tile is a wall collision in the engine (reference: AssertionError, BE:514) */
+    }
+    return wall;
+}
+
+static int pair_any(const env_ctx *c, const double *xy, int add_safety, double *margin) {
+    double qpos[GPRO_MAX_MOVERS * 7];
+    make_qpos(c->cfg->num_movers, xy, qpos);
+    return gpro_check_mover_collision(&c->cfg->lay, c->cfg->num_movers, qpos, c->cfg->c_size, add_safety, margin);
+}
+
+/* _get_obs (PL:536-573) + _get_info (PL:575-602) + reward/terminated (PL:459-534) */
+static void observe(const env_ctx *c, gpro_rng *rng, const double *pos, const double *vel, const double *acc, const double *goal,
+                    int mc, int wc, int64_t e, gpro_step_out *out, double *margin) {
+    const gpro_env_cfg *cfg = c->cfg;
+    int M = cfg->num_movers;
+    int od = cfg->learn_jerk ? 4 * M : 2 * M;
+    double npos[GPRO_MAX_MOVERS * 2], nvel[GPRO_MAX_MOVERS * 2];
+    noisy(c, rng, M, pos, cfg->std_noise[0], npos); /* PL:554 */
+    noisy(c, rng, M, vel, cfg->std_noise[1], nvel); /* PL:555 */
+    for (int k = 0; k < 2 * M; ++k) {
+        out->observation[od * e + k] = q32(cfg, nvel[k]);
+        if (cfg->learn_jerk) out->observation[od * e + 2 * M + k] = q32(cfg, acc[k]); /* PL:558-560: no noise, after all velocities */
+        out->achieved_goal[2 * M * e + k] = q32(cfg, npos[k]);
+        out->desired_goal[2 * M * e + k] = q32(cfg, goal[k]);
+    }
+    double r; uint8_t term, succ;
+    reward_one(M, &out->achieved_goal[2 * M * e], &out->desired_goal[2 * M * e], mc, wc, cfg->threshold_pos, cfg->reward_success, &r,
+               &term, &succ, margin);
+    out->reward[e] = r;
+    out->terminated[e] = term;
+    out->is_success[e] = succ;
+    out->mover_collision[e] = (uint8_t)mc;
+    out->wall_collision[e] = (uint8_t)wc;
+}
+
+/* _reset_callback (PL:355-418) + reset() (BE:1770-1833) for one env; leaves the reset observation in out. */
+static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t env_id, int64_t e, double *pos, double *vel, double *acc,
+                      double *goal, int32_t *elapsed, gpro_step_out *out, double *margin) {
+    const gpro_env_cfg *cfg = c->cfg;
+    int M = cfg->num_movers;
+    gpro_rng rng;
+    gpro_rng_seed(&rng, seed, (uint64_t)env_id, tick, 2u);
+    double xy[GPRO_MAX_MOVERS * 2];
+    for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PL:369-385 */
+        for (int k = 0; k < 2 * M; ++k) {
+            int d = k & 1;
+            double u = gpro_rng_uniform(&rng);
+            xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:377 */
+        }
+        int wall = wall_any(c, xy, 1, margin);  /* PL:379 add_safety_offset=True */
+        int coll = pair_any(c, xy, 1, margin);  /* PL:381-383 */
+        if (!coll && !wall) break;
+    }
+    memcpy(pos, xy, sizeof(double) * 2 * M);
+    for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PL:395-413 */
+        for (int k = 0; k < 2 * M; ++k) {
+            int d = k & 1;
+            double u = gpro_rng_uniform(&rng);
+            xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:402 */
+        }
+        int wall = wall_any(c, xy, 1, margin); /* PL:403-404 */
+        int ok = !wall;
+        if (ok) {
+            for (int i = 0; i < M && ok; ++i) for (int j = i + 1; j < M; ++j) { /* PL:407-413 */
+                double dx = xy[2 * i] - xy[2 * j], dy = xy[2 * i + 1] - xy[2 * j + 1];
+                double dist = sqrt(dx * dx + dy * dy);
+                track(margin, dist, cfg->min_goal_dist);
+                if (dist < cfg->min_goal_dist) { ok = 0; break; }
+            }
+        }
+        if (ok) break;
+    }
+    memcpy(goal, xy, sizeof(double) * 2 * M);
+    for (int k = 0; k < 2 * M; ++k) { vel[k] = 0.0; acc[k] = 0.0; } /* reload_model + mj_forward: v = 0, act = 0, qacc = 0 */
+    *elapsed = 0;
+    double tmp[GPRO_MAX_MOVERS * 2];
+    noisy(c, &rng, M, pos, cfg->std_noise[0], tmp);
+    int wc = wall_any(c, tmp, 1, margin); /* BE:1799-1801 add_safety_offset=True */
+    noisy(c, &rng, M, pos, cfg->std_noise[0], tmp);
+    int mc = pair_any(c, tmp, 0, margin); /* BE:1803-1805 add_safety_offset=False */
+    observe(c, &rng, pos, vel, acc, goal, mc, wc, e, out, margin);
+    out->truncated[e] = 0;
+}
+
+static void ctx_init(env_ctx *c, const gpro_env_cfg *cfg) {
+    c->cfg = cfg;
+    gpro_tile_centres(cfg->lay.num_tiles_x, cfg->lay.tile_hx, c->xc);
+    gpro_tile_centres(cfg->lay.num_tiles_y, cfg->lay.tile_hy, c->yc);
+    c->noise = cfg->std_noise[0] != 0.0 || cfg->std_noise[1] != 0.0 || cfg->std_noise[2] != 0.0;
+}
+
+int32_t gpro_planning_reset(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset,
+                            const uint8_t *mask, double *pos, double *vel, double *acc, double *goal, int32_t *elapsed,
+                            gpro_step_out *out) {
+    if (cfg->num_movers < 1 || cfg->num_movers > GPRO_MAX_MOVERS) return -1;
+    env_ctx c;
+    ctx_init(&c, cfg);
+    int M = cfg->num_movers;
+    for (int64_t e = 0; e < num_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        double m = INFINITY;
+        reset_one(&c, seed, tick, env_id_offset + e, e, pos + 2 * M * e, vel + 2 * M * e, acc + 2 * M * e, goal + 2 * M * e, elapsed + e,
+                  out, out->margin ? &m : NULL);
+        out->reward[e] = 0.0;
+        out->terminated[e] = 0;
+        if (out->margin) out->margin[e] = m;
+    }
+    return 0;
+}
+
+static void step_range(const env_ctx *c, int64_t e0, int64_t e1, uint64_t seed, uint64_t tick, int64_t env_id_offset, const double *action,
+                       double *pos_a, double *vel_a, double *acc_a, double *goal_a, int32_t *elapsed_a, int32_t autoreset, gpro_step_out *out) {
+    const gpro_env_cfg *cfg = c->cfg;
+    const int M = cfg->num_movers;
+    const int od = cfg->learn_jerk ? 4 * M : 2 * M;
+    const double dt = cfg->dt;
+    for (int64_t e = e0; e < e1; ++e) {
+        double *pos = pos_a + 2 * M * e, *vel = vel_a + 2 * M * e, *acc = acc_a + 2 * M * e, *goal = goal_a + 2 * M * e;
+        double m = INFINITY;
+        double *margin = out->margin ? &m : NULL;
+        if (autoreset == 2 && elapsed_a[e] < 0) { /* next-step autoreset: the action is ignored (Gymnasium AutoresetMode.NEXT_STEP) */
+            reset_one(c, seed, tick, env_id_offset + e, e, pos, vel, acc, goal, elapsed_a + e, out, margin);
+            out->reward[e] = 0.0;
+            out->terminated[e] = 0;
+            if (out->margin) out->margin[e] = m;
+            continue;
+        }
+        gpro_rng rng;
+        gpro_rng_seed(&rng, seed, (uint64_t)(env_id_offset + e), tick, 1u);
+        /* BE:1869-1873: clip to the action space (+-a_max, or +-j_max when learn_jerk; PL:257-259) */
+        double lim = cfg->learn_jerk ? cfg->j_max : cfg->a_max;
+        double a[GPRO_MAX_MOVERS * 2];
+        for (int k = 0; k < 2 * M; ++k) a[k] = fmin(fmax(action[2 * M * e + k], -lim), lim);
+        int wc = 0, mc = 0;
+        for (int cyc = 0; cyc < cfg->num_cycles; ++cyc) { /* BE:1879 */
+            /* _mujoco_step_callback (PL:420-450) */
+            double nv[GPRO_MAX_MOVERS * 2], u[GPRO_MAX_MOVERS * 2];
+            noisy(c, &rng, M, vel, cfg->std_noise[1], nv); /* PL:430 */
+            for (int i = 0; i < M; ++i) {
+                double vals[2], ders[2];
+                if (cfg->learn_jerk) { /* PL:432-440 */
+                    double acc_tmp[2], j1[2];
+                    clamp_one(acc + 2 * i, cfg->a_max, a + 2 * i, dt, acc_tmp, j1, margin);
+                    clamp_one(nv + 2 * i, cfg->v_max, acc_tmp, dt, vals, ders, margin);
+                    if (acc_tmp[0] != ders[0] || acc_tmp[1] != ders[1]) {
+                        u[2 * i] = (ders[0] - acc[2 * i]) / dt;
+                        u[2 * i + 1] = (ders[1] - acc[2 * i + 1]) / dt;
+                    } else {
+                        u[2 * i] = j1[0]; u[2 * i + 1] = j1[1];
+                    }
+                } else { /* PL:442-443 */
+                    clamp_one(nv + 2 * i, cfg->v_max, a + 2 * i, dt, vals, ders, margin);
+                    u[2 * i] = ders[0]; u[2 * i + 1] = ders[1];
+                }
+            }
+            /* mj_step (BE:1882) for the MJCF of BE:878-883,1132 + PL:305-319: qacc = ctrl (or the integrated activation,
+             * actearly), semi-implicit Euler: v += dt*qacc; p += dt*v_new. Equivalence asserted by the reference's own
+             * tests (tests/test_benchmark_planning_env.py:86-121,199-231). */
+            for (int k = 0; k < 2 * M; ++k) {
+                double qacc;
+                if (cfg->learn_jerk) { acc[k] = acc[k] + dt * u[k]; qacc = acc[k]; }
+                else { qacc = u[k]; acc[k] = qacc; }
+                vel[k] = vel[k] + dt * qacc;
+                pos[k] = pos[k] + dt * vel[k];
+            }
+            double np_[GPRO_MAX_MOVERS * 2];
+            noisy(c, &rng, M, pos, cfg->std_noise[0], np_);
+            wc = wall_any(c, np_, 0, margin); /* BE:1888-1894 */
+            noisy(c, &rng, M, pos, cfg->std_noise[0], np_);
+            mc = pair_any(c, np_, 0, margin); /* BE:1895-1901 */
+            if (mc || wc) break;              /* BE:1904-1905 */
+        }
+        for (int k = 0; k < 2 * M; ++k) { pos[k] = q32(cfg, pos[k]); vel[k] = q32(cfg, vel[k]); acc[k] = q32(cfg, acc[k]); }
+        observe(c, &rng, pos, vel, acc, goal, mc, wc, e, out, margin);
+        elapsed_a[e] += 1;
+        int trunc = cfg->max_episode_steps > 0 && elapsed_a[e] >= cfg->max_episode_steps; /* gymnasium TimeLimit */
+        out->truncated[e] = (uint8_t)trunc;
+        int done = out->terminated[e] || trunc;
+        if (done && autoreset == 1) {
+            if (out->final_observation) memcpy(out->final_observation + od * e, out->observation + od * e, sizeof(double) * od);
+            if (out->final_achieved_goal) memcpy(out->final_achieved_goal + 2 * M * e, out->achieved_goal + 2 * M * e, sizeof(double) * 2 * M);
+            if (out->final_desired_goal) memcpy(out->final_desired_goal + 2 * M * e, out->desired_goal + 2 * M * e, sizeof(double) * 2 * M);
+            double r = out->reward[e];
+            uint8_t t = out->terminated[e], s = out->is_success[e], pm = out->mover_collision[e], pw = out->wall_collision[e];
+            reset_one(c, seed, tick, env_id_offset + e, e, pos, vel, acc, goal, elapsed_a + e, out, margin);
+            out->reward[e] = r; out->terminated[e] = t; out->truncated[e] = (uint8_t)trunc;
+            out->is_success[e] = s; out->mover_collision[e] = pm; out->wall_collision[e] = pw;
+        } else if (done && autoreset == 2) {
+            elapsed_a[e] = -1;
+        }
+        if (out->margin) out->margin[e] = m;
+    }
+}
+
+int32_t gpro_planning_step(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset,
+                           const double *action, double *pos, double *vel, double *acc, double *goal, int32_t *elapsed, int32_t autoreset,
+                           gpro_step_out *out) {
+    if (cfg->num_movers < 1 || cfg->num_movers > GPRO_MAX_MOVERS) return -1;
+    env_ctx c;
+    ctx_init(&c, cfg);
+    step_range(&c, 0, num_envs, seed, tick, env_id_offset, action, pos, vel, acc, goal, elapsed, autoreset, out);
+    return 0;
+}
+
+typedef struct {
+    const env_ctx *c; int64_t e0, e1; uint64_t seed, tick; int64_t off; const double *action;
+    double *pos, *vel, *acc, *goal; int32_t *elapsed; int32_t autoreset; gpro_step_out *out;
+} mt_arg;
+
+static void *mt_worker(void *p) {
+    mt_arg *a = (mt_arg *)p;
+    step_range(a->c, a->e0, a->e1, a->seed, a->tick, a->off, a->action, a->pos, a->vel, a->acc, a->goal, a->elapsed, a->autoreset, a->out);
+    return NULL;
+}
+
+int32_t gpro_planning_step_mt(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset,
+                              const double *action, double *pos, double *vel, double *acc, double *goal, int32_t *elapsed, int32_t autoreset,
+                              gpro_step_out *out, int32_t num_threads) {
+    if (cfg->num_movers < 1 || cfg->num_movers > GPRO_MAX_MOVERS) return -1;
+    if (num_threads < 1) num_threads = 1;
+    if (num_threads > 256) num_threads = 256;
+    env_ctx c;
+    ctx_init(&c, cfg);
+    pthread_t th[256];
+    mt_arg args[256];
+    int64_t per = (num_envs + num_threads - 1) / num_threads;
+    int n = 0;
+    for (int t = 0; t < num_threads; ++t) {
+        int64_t e0 = t * per, e1 = e0 + per > num_envs ? num_envs : e0 + per;
+        if (e0 >= e1) break;
+        args[n] = (mt_arg){&c, e0, e1, seed, tick, env_id_offset, action, pos, vel, acc, goal, elapsed, autoreset, out};
+        pthread_create(&th[n], NULL, mt_worker, &args[n]);
+        ++n;
+    }
+    for (int t = 0; t < n; ++t) pthread_join(th[t], NULL);
+    return 0;
+}
