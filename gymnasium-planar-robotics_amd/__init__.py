@@ -1,0 +1,11 @@
+"""MI355X-native vectorised planar-robotics environments: a drop-in for the per-env hot path of
+ubi-coro/gymnasium-planar-robotics (BenchmarkPlanningEnv step()/reset(), collision checks, geometry_2D_utils), batched and
+executed by hand-written HIP kernels (gfx950) behind the C ABI of include/gpr.h. See DESIGN.md."""
+__version__ = '0.1.0'
+
+from . import _native, spaces
+from .envs.basic_envs import VecBasicPlanarRoboticsEnv
+from .envs.planning.benchmark_planning_env import VecBenchmarkPlanningEnv
+from .utils import geometry_2D_utils
+
+__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'geometry_2D_utils', 'spaces', '_native']

@@ -1,0 +1,388 @@
+// gpr_api.hip -- the C ABI of libgpr_hip.so (include/gpr.h): handle management, ctor-time tables, launch plumbing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/gpr.h"
+#include "gpr_host.h"
+
+using namespace gpr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct TableSet {
+    void *dev = nullptr;
+    uint32_t bytes = 0, off_ax = 0, off_ay = 0, off_lut = 0, off_nbr = 0, off_csz = 0, off_cx = 0, off_cy = 0;
+};
+
+}  // namespace
+
+struct gpr_env {
+    gpr_config cfg{};
+    std::vector<int8_t> layout;
+    std::vector<double> xc, yc, csize;
+    TableSet tab_f32, tab_f64;
+    KParams base{};
+    gpr_state state{};
+    bool bound = false;
+    uint64_t seed = 0, tick = 0;
+    int lpe = 1;
+    mutable std::string err;
+};
+
+namespace {
+
+int fail(gpr_env *env, int code, const std::string &msg) {
+    if (env) env->err = msg; else g_create_error = msg;
+    return code;
+}
+int fail_hip(gpr_env *env, hipError_t e, const char *what) {
+    return fail(env, GPR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// numpy.linspace(w/2, (n-1)*w + w/2, n) as get_tile_xy_pos uses it (BE:1292-1310); used when the caller passes no centres
+std::vector<double> tile_centres(int n, double half) {
+    std::vector<double> out((size_t)n);
+    const double w = half * 2, start = w / 2, stop = (n - 1) * w + w / 2;
+    const double step = n > 1 ? (stop - start) / (n - 1) : 0.0;
+    for (int i = 0; i < n; ++i) out[(size_t)i] = i * step + start;
+    if (n > 1) out[(size_t)n - 1] = stop;
+    return out;
+}
+
+int tile_at(const gpr_env &e, int ix, int iy) {  // layout_tiles_wc (BE:221): anything outside the layout is "no tile"
+    if (ix < 0 || iy < 0 || ix >= e.cfg.num_tiles_x || iy >= e.cfg.num_tiles_y) return 0;
+    return e.layout[(size_t)ix * e.cfg.num_tiles_y + iy];
+}
+
+// mask_valid of BE:580-648 for one tile as a function of the four "safe" compares (bit0 min_x, bit1 max_x, bit2 min_y,
+// bit3 max_y), stored as 16 x 2 bits. For a missing tile every compare is multiplied by layout == 0, so every entry is 0.
+uint32_t tile_lut(const gpr_env &e, int ix, int iy) {
+    const int L = tile_at(e, ix, iy);
+    const int left = tile_at(e, ix - 1, iy), right = tile_at(e, ix + 1, iy), down = tile_at(e, ix, iy - 1), up = tile_at(e, ix, iy + 1);
+    const int ld = tile_at(e, ix - 1, iy - 1), lu = tile_at(e, ix - 1, iy + 1), rd = tile_at(e, ix + 1, iy - 1), ru = tile_at(e, ix + 1, iy + 1);
+    uint32_t lut = 0;
+    for (int bits = 0; bits < 16; ++bits) {
+        const int mnx = L * (bits & 1), mxx = L * ((bits >> 1) & 1), mny = L * ((bits >> 2) & 1), mxy = L * ((bits >> 3) & 1);
+        int mv = mnx * mxx * mny * mxy;                  // BE:580
+        const int u_mnx = (1 - mnx) * (L * left);        // BE:583-586 (index masks are implied: outside == no tile)
+        mv += u_mnx * mny * mxy;                         // BE:587
+        mv += u_mnx * ((1 - mny) * (L * down * ld));     // BE:589-597
+        mv += u_mnx * ((1 - mxy) * (L * up * lu));       // BE:599-607
+        const int u_mxx = (1 - mxx) * (L * right);       // BE:610-613
+        mv += u_mxx * mny * mxy;                         // BE:614
+        mv += u_mxx * ((1 - mny) * (L * down * rd));     // BE:616-624
+        mv += u_mxx * ((1 - mxy) * (L * up * ru));       // BE:626-634
+        mv += ((1 - mny) * (L * down)) * mnx * mxx;      // BE:637-641
+        mv += ((1 - mxy) * (L * up)) * mnx * mxx;        // BE:644-648
+        lut |= (uint32_t)(mv > 3 ? 3 : mv) << (2 * bits);
+    }
+    return lut;
+}
+
+template <typename RT> void put(std::vector<uint8_t> &blob, uint32_t off, size_t i, RT v) { std::memcpy(blob.data() + off + i * sizeof(RT), &v, sizeof(RT)); }
+
+template <typename RT> int build_tables(gpr_env *e, TableSet &ts) {
+    const int Tx = e->cfg.num_tiles_x, Ty = e->cfg.num_tiles_y;
+    const double hx = e->cfg.tile_half_size[0], hy = e->cfg.tile_half_size[1];
+    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+    uint32_t off = 0;
+    ts.off_ax = off; off = align16(off + (uint32_t)(Tx * 4 * sizeof(RT)));
+    ts.off_ay = off; off = align16(off + (uint32_t)(Ty * 4 * sizeof(RT)));
+    ts.off_lut = off; off = align16(off + (uint32_t)(Tx * Ty * 4));
+    ts.off_nbr = off; off = align16(off + (uint32_t)(Tx * Ty * 2));
+    ts.off_csz = off; off = align16(off + (uint32_t)(GPR_MAX_MOVERS * 2 * sizeof(RT)));
+    ts.off_cx = off; off = align16(off + (uint32_t)(Tx * sizeof(RT)));
+    ts.off_cy = off; off = align16(off + (uint32_t)(Ty * sizeof(RT)));
+    ts.bytes = off;
+    std::vector<uint8_t> blob(off, 0);
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int i = 0; i < Tx; ++i) {  // edges exactly as BE:509-510 / BE:522-523 form them: centre -/+ half size, in f64
+        put<RT>(blob, ts.off_ax, (size_t)4 * i + 0, (RT)(e->xc[(size_t)i] - hx));
+        put<RT>(blob, ts.off_ax, (size_t)4 * i + 1, (RT)(e->xc[(size_t)i] + hx));
+        put<RT>(blob, ts.off_ax, (size_t)4 * i + 2, (RT)(i > 0 ? e->xc[(size_t)i - 1] + hx : -inf));
+        put<RT>(blob, ts.off_ax, (size_t)4 * i + 3, (RT)(i < Tx - 1 ? e->xc[(size_t)i + 1] - hx : inf));
+        put<RT>(blob, ts.off_cx, (size_t)i, (RT)e->xc[(size_t)i]);
+    }
+    for (int i = 0; i < Ty; ++i) {
+        put<RT>(blob, ts.off_ay, (size_t)4 * i + 0, (RT)(e->yc[(size_t)i] - hy));
+        put<RT>(blob, ts.off_ay, (size_t)4 * i + 1, (RT)(e->yc[(size_t)i] + hy));
+        put<RT>(blob, ts.off_ay, (size_t)4 * i + 2, (RT)(i > 0 ? e->yc[(size_t)i - 1] + hy : -inf));
+        put<RT>(blob, ts.off_ay, (size_t)4 * i + 3, (RT)(i < Ty - 1 ? e->yc[(size_t)i + 1] - hy : inf));
+        put<RT>(blob, ts.off_cy, (size_t)i, (RT)e->yc[(size_t)i]);
+    }
+    for (int ix = 0; ix < Tx; ++ix)
+        for (int iy = 0; iy < Ty; ++iy) {
+            put<uint32_t>(blob, ts.off_lut, (size_t)ix * Ty + iy, tile_lut(*e, ix, iy));
+            uint16_t n = 0;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    if (tile_at(*e, ix + dx, iy + dy)) n |= (uint16_t)(1u << ((dx + 1) * 3 + (dy + 1)));
+            put<uint16_t>(blob, ts.off_nbr, (size_t)ix * Ty + iy, n);
+        }
+    for (int i = 0; i < e->cfg.num_movers * 2; ++i) put<RT>(blob, ts.off_csz, (size_t)i, (RT)e->csize[(size_t)i]);
+    hipError_t he = hipMalloc(&ts.dev, ts.bytes);
+    if (he != hipSuccess) return fail_hip(e, he, "hipMalloc(tables)");
+    he = hipMemcpy(ts.dev, blob.data(), ts.bytes, hipMemcpyHostToDevice);
+    if (he != hipSuccess) return fail_hip(e, he, "hipMemcpy(tables)");
+    return GPR_OK;
+}
+
+template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
+    const gpr_config &g = e.cfg;
+    c.dt = (RT)g.cycle_time; c.inv_dt = (RT)(1.0 / g.cycle_time);
+    c.v_max = (RT)g.v_max; c.a_max = (RT)g.a_max; c.j_max = (RT)g.j_max; c.thr = (RT)g.threshold_pos;
+    c.sig_p = (RT)g.std_noise[0]; c.sig_v = (RT)g.std_noise[1]; c.sig_a = (RT)g.std_noise[2];
+    c.inv_wx = (RT)(1.0 / (2.0 * g.tile_half_size[0])); c.inv_wy = (RT)(1.0 / (2.0 * g.tile_half_size[1]));
+    c.min_x = (RT)g.min_xy_pos[0]; c.min_y = (RT)g.min_xy_pos[1]; c.max_x = (RT)g.max_xy_pos[0]; c.max_y = (RT)g.max_xy_pos[1];
+    c.min_goal_dist = (RT)g.min_goal_dist; c.reward_success = (RT)50.0;  // PL:220
+    c.c_offset = (RT)g.c_offset; c.c_offset_wall = (RT)g.c_offset_wall;
+    c.tile_hx = (RT)g.tile_half_size[0]; c.tile_hy = (RT)g.tile_half_size[1];
+    // BE:390 + BE:409: largest (c_i + off) + (c_j + off) over mover pairs; -1 when there is no pair (never <= a distance)
+    double ms = -1.0, mf = -1.0;
+    for (int i = 0; i < g.num_movers - 1; ++i)
+        for (int j = i + 1; j < g.num_movers; ++j) {
+            double ci = e.csize[(size_t)2 * i], cj = e.csize[(size_t)2 * j];
+            double s0 = (ci + g.c_offset * 0.0) + (cj + g.c_offset * 0.0), s1 = (ci + g.c_offset * 1.0) + (cj + g.c_offset * 1.0);
+            ms = s0 > ms ? s0 : ms; mf = s1 > mf ? s1 : mf;
+        }
+    c.max_csum_step = (RT)ms; c.max_csum_safe = (RT)mf;
+}
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+
+KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
+    KParams P = e->base;
+    const TableSet &ts = (is_f64_ops || e->cfg.precision != GPR_PRECISION_F32 || e->cfg.learn_jerk) ? e->tab_f64 : e->tab_f32;
+    P.tables = ts.dev; P.table_bytes = ts.bytes;
+    P.off_ax = ts.off_ax; P.off_ay = ts.off_ay; P.off_lut = ts.off_lut; P.off_nbr = ts.off_nbr; P.off_csz = ts.off_csz;
+    P.off_cx = ts.off_cx; P.off_cy = ts.off_cy;
+    P.seed_lo = (uint32_t)e->seed; P.seed_hi = (uint32_t)(e->seed >> 32);
+    P.tick_lo = (uint32_t)e->tick; P.tick_hi = (uint32_t)(e->tick >> 32);
+    P.pos = e->state.pos_dev; P.vel = e->state.vel_dev; P.acc = e->state.acc_dev; P.goal = e->state.goal_dev;
+    P.elapsed = e->state.elapsed_dev;
+    if (out) {
+        P.obs = out->observation_dev; P.ag = out->achieved_goal_dev; P.dg = out->desired_goal_dev; P.reward = out->reward_dev;
+        P.terminated = out->terminated_dev; P.truncated = out->truncated_dev; P.is_success = out->is_success_dev;
+        P.mover_collision = out->mover_collision_dev; P.wall_collision = out->wall_collision_dev;
+        P.final_obs = out->final_observation_dev; P.final_ag = out->final_achieved_goal_dev; P.final_dg = out->final_desired_goal_dev;
+    }
+    return P;
+}
+
+int check_out(gpr_env *e, const gpr_step_out *o) {
+    if (!o) return fail(e, GPR_E_INVALID, "gpr_step_out is NULL");
+    if (!o->observation_dev || !o->achieved_goal_dev || !o->desired_goal_dev || !o->reward_dev || !o->terminated_dev || !o->truncated_dev ||
+        !o->is_success_dev || !o->mover_collision_dev || !o->wall_collision_dev)
+        return fail(e, GPR_E_INVALID, "gpr_step_out: every non-final_* pointer must be set");
+    const bool any_final = o->final_observation_dev || o->final_achieved_goal_dev || o->final_desired_goal_dev;
+    const bool all_final = o->final_observation_dev && o->final_achieved_goal_dev && o->final_desired_goal_dev;
+    if (any_final && !all_final) return fail(e, GPR_E_INVALID, "gpr_step_out: set all three final_* pointers or none");
+    return GPR_OK;
+}
+
+int launch_env(gpr_env *e, bool is_reset, const KParams &P, hipStream_t s) {
+    hipError_t he;
+    switch (e->cfg.precision) {
+        case GPR_PRECISION_F32:
+            // jerk mode integrates in double even with float storage (see launch_flags in gpr_env_kernels.hip)
+            he = e->cfg.learn_jerk ? launch_env_kernel<float, double>(is_reset, e->lpe, P, s)
+                                   : launch_env_kernel<float, float>(is_reset, e->lpe, P, s);
+            break;
+        case GPR_PRECISION_F32_F64ACC: he = launch_env_kernel<float, double>(is_reset, e->lpe, P, s); break;
+        default: he = launch_env_kernel<double, double>(is_reset, e->lpe, P, s); break;
+    }
+    if (he != hipSuccess) return fail_hip(e, he, is_reset ? "reset kernel launch" : "step kernel launch");
+    return GPR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gpr_version(void) { return "gpr-hip 0.1 (gfx950; rng gpr-rng-v1; one lane per mover)"; }
+
+const char *gpr_last_error(const gpr_env *env) { return env ? env->err.c_str() : g_create_error.c_str(); }
+
+int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
+    if (!cfg || !out_env) return fail(nullptr, GPR_E_INVALID, "gpr_create: NULL argument");
+    *out_env = nullptr;
+    const gpr_config &c = *cfg;
+    if (c.num_envs < 1) return fail(nullptr, GPR_E_INVALID, "num_envs must be >= 1");
+    if (c.num_movers < 1 || c.num_movers > GPR_MAX_MOVERS) return fail(nullptr, GPR_E_INVALID, "num_movers must be in [1, 16]");
+    if (c.num_tiles_x < 1 || c.num_tiles_y < 1 || (int64_t)c.num_tiles_x * c.num_tiles_y > GPR_MAX_TILES)
+        return fail(nullptr, GPR_E_INVALID, "tile layout must have between 1 and 4096 cells");
+    if (!c.layout_tiles || !c.c_size) return fail(nullptr, GPR_E_INVALID, "layout_tiles and c_size are required");
+    if (!(c.tile_half_size[0] > 0) || !(c.tile_half_size[1] > 0)) return fail(nullptr, GPR_E_INVALID, "tile_half_size must be > 0");
+    if (c.c_shape != GPR_SHAPE_CIRCLE && c.c_shape != GPR_SHAPE_BOX) return fail(nullptr, GPR_E_INVALID, "c_shape must be circle or box");
+    if (!(c.cycle_time > 0) || c.num_cycles < 0) return fail(nullptr, GPR_E_INVALID, "cycle_time must be > 0 and num_cycles >= 0");
+    if (c.autoreset_mode < GPR_AUTORESET_DISABLED || c.autoreset_mode > GPR_AUTORESET_NEXT_STEP)
+        return fail(nullptr, GPR_E_INVALID, "unknown autoreset_mode");
+    if (c.precision < GPR_PRECISION_F32 || c.precision > GPR_PRECISION_F64) return fail(nullptr, GPR_E_INVALID, "unknown precision");
+    if (c.max_reset_trials < 1) return fail(nullptr, GPR_E_INVALID, "max_reset_trials must be >= 1");
+    for (int d = 0; d < 3; ++d)
+        if (!(c.std_noise[d] >= 0)) return fail(nullptr, GPR_E_INVALID, "std_noise must be >= 0");
+    int n_tiles = 0;
+    for (int64_t i = 0; i < (int64_t)c.num_tiles_x * c.num_tiles_y; ++i) {
+        if (c.layout_tiles[i] != 0 && c.layout_tiles[i] != 1) return fail(nullptr, GPR_E_INVALID, "layout_tiles must contain only 0 and 1");
+        n_tiles += c.layout_tiles[i];
+    }
+    if (n_tiles == 0) return fail(nullptr, GPR_E_INVALID, "layout_tiles has no tile");
+
+    gpr_env *e = new gpr_env();
+    e->cfg = c;
+    e->layout.assign(c.layout_tiles, c.layout_tiles + (size_t)c.num_tiles_x * c.num_tiles_y);
+    e->xc = c.tile_x_centres ? std::vector<double>(c.tile_x_centres, c.tile_x_centres + c.num_tiles_x) : tile_centres(c.num_tiles_x, c.tile_half_size[0]);
+    e->yc = c.tile_y_centres ? std::vector<double>(c.tile_y_centres, c.tile_y_centres + c.num_tiles_y) : tile_centres(c.num_tiles_y, c.tile_half_size[1]);
+    e->csize.assign(c.c_size, c.c_size + (size_t)c.num_movers * 2);
+    e->cfg.layout_tiles = e->layout.data();
+    e->cfg.tile_x_centres = e->xc.data();
+    e->cfg.tile_y_centres = e->yc.data();
+    e->cfg.c_size = e->csize.data();
+    e->lpe = next_pow2(c.num_movers);
+
+    int rc = build_tables<float>(e, e->tab_f32);
+    if (rc == GPR_OK) rc = build_tables<double>(e, e->tab_f64);
+    if (rc != GPR_OK) {
+        g_create_error = e->err;
+        gpr_destroy(e);
+        return rc;
+    }
+    KParams &P = e->base;
+    P.E = c.num_envs; P.env_id_offset = c.env_id_offset;
+    P.M = c.num_movers; P.Tx = c.num_tiles_x; P.Ty = c.num_tiles_y; P.c_shape = c.c_shape;
+    P.num_cycles = c.num_cycles; P.max_episode_steps = c.max_episode_steps; P.autoreset = c.autoreset_mode;
+    P.max_reset_trials = c.max_reset_trials; P.learn_jerk = c.learn_jerk != 0;
+    P.noise = (c.std_noise[0] != 0.0) || (c.std_noise[1] != 0.0) || (c.std_noise[2] != 0.0);
+    fill_cst<float>(*e, P.cf);
+    fill_cst<double>(*e, P.cd);
+    *out_env = e;
+    return GPR_OK;
+}
+
+void gpr_destroy(gpr_env *env) {
+    if (!env) return;
+    if (env->tab_f32.dev) (void)hipFree(env->tab_f32.dev);
+    if (env->tab_f64.dev) (void)hipFree(env->tab_f64.dev);
+    delete env;
+}
+
+int gpr_bind_state(gpr_env *env, const gpr_state *state) {
+    if (!env || !state) return fail(env, GPR_E_INVALID, "gpr_bind_state: NULL argument");
+    if (!state->pos_dev || !state->vel_dev || !state->acc_dev || !state->goal_dev || !state->elapsed_dev)
+        return fail(env, GPR_E_INVALID, "gpr_bind_state: every state pointer must be set");
+    env->state = *state;
+    env->bound = true;
+    return GPR_OK;
+}
+
+int gpr_seed(gpr_env *env, uint64_t seed) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_seed: NULL handle");
+    env->seed = seed;
+    env->tick = 0;
+    return GPR_OK;
+}
+
+int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_reset: NULL handle");
+    if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_reset: call gpr_bind_state first");
+    if (env->cfg.c_shape != GPR_SHAPE_CIRCLE) return fail(env, GPR_E_UNSUPPORTED, "gpr_reset: the fused env kernels support the 'circle' collision shape");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    KParams P = make_params(env, out, false);
+    P.mask = mask_dev;
+    rc = launch_env(env, true, P, as_stream(hip_stream));
+    if (rc == GPR_OK) env->tick += 1;
+    return rc;
+}
+
+int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_step: NULL handle");
+    if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_step: call gpr_bind_state first");
+    if (!action_dev) return fail(env, GPR_E_INVALID, "gpr_step: action is NULL");
+    if (env->cfg.c_shape != GPR_SHAPE_CIRCLE) return fail(env, GPR_E_UNSUPPORTED, "gpr_step: the fused env kernels support the 'circle' collision shape");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    KParams P = make_params(env, out, false);
+    P.action = action_dev;
+    rc = launch_env(env, false, P, as_stream(hip_stream));
+    if (rc == GPR_OK) env->tick += 1;
+    return rc;
+}
+
+int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, const void *desired_dev, const uint8_t *mover_collision_dev,
+                       const uint8_t *wall_collision_dev, void *reward_dev, uint8_t *terminated_dev, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_compute_reward: NULL handle");
+    if (batch == 0) return GPR_OK;
+    if (batch < 0 || !achieved_dev || !desired_dev || !mover_collision_dev || !wall_collision_dev || !reward_dev)
+        return fail(env, GPR_E_INVALID, "gpr_compute_reward: bad argument");
+    KParams P = make_params(env, nullptr, true);
+    hipError_t he = env->cfg.precision == GPR_PRECISION_F64
+                        ? launch_reward<double>(P, batch, achieved_dev, desired_dev, mover_collision_dev, wall_collision_dev, reward_dev, terminated_dev, as_stream(hip_stream))
+                        : launch_reward<float>(P, batch, achieved_dev, desired_dev, mover_collision_dev, wall_collision_dev, reward_dev, terminated_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(env, he, "reward kernel launch");
+}
+
+int gpr_qpos_is_valid(gpr_env *env, int64_t n, const double *qpos_dev, const double *c_size_dev, int32_t add_safety_offset, int32_t *out_dev,
+                      void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_qpos_is_valid: NULL handle");
+    if (n == 0) return GPR_OK;
+    if (n < 0 || !qpos_dev || !c_size_dev || !out_dev) return fail(env, GPR_E_INVALID, "gpr_qpos_is_valid: bad argument");
+    KParams P = make_params(env, nullptr, true);
+    hipError_t he = launch_qpos_valid(P, n, qpos_dev, c_size_dev, add_safety_offset, out_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(env, he, "qpos_is_valid kernel launch");
+}
+
+int gpr_check_mover_collision(gpr_env *env, int64_t batch, const double *qpos_dev, const double *c_size_dev, int32_t add_safety_offset,
+                              uint8_t *out_dev, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_check_mover_collision: NULL handle");
+    if (batch == 0) return GPR_OK;
+    if (batch < 0 || !qpos_dev || !c_size_dev || !out_dev) return fail(env, GPR_E_INVALID, "gpr_check_mover_collision: bad argument");
+    KParams P = make_params(env, nullptr, true);
+    hipError_t he = launch_mover_collision(P, batch, qpos_dev, c_size_dev, add_safety_offset, out_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(env, he, "mover collision kernel launch");
+}
+
+int gpr_check_line_segments_intersect(int64_t n, const double *p1_dev, const double *p2_dev, const double *q1_dev, const double *q2_dev,
+                                      uint8_t *out_dev, void *hip_stream) {
+    if (n == 0) return GPR_OK;
+    if (n < 0 || !p1_dev || !p2_dev || !q1_dev || !q2_dev || !out_dev) return fail(nullptr, GPR_E_INVALID, "gpr_check_line_segments_intersect: bad argument");
+    hipError_t he = launch_segments(n, p1_dev, p2_dev, q1_dev, q2_dev, out_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(nullptr, he, "segments kernel launch");
+}
+
+int gpr_get_2D_rect_vertices(int64_t n, const double *qpos_dev, const double *size_dev, double *out_dev, void *hip_stream) {
+    if (n == 0) return GPR_OK;
+    if (n < 0 || !qpos_dev || !size_dev || !out_dev) return fail(nullptr, GPR_E_INVALID, "gpr_get_2D_rect_vertices: bad argument");
+    hipError_t he = launch_rect_vertices(n, qpos_dev, size_dev, out_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(nullptr, he, "rect vertices kernel launch");
+}
+
+int gpr_check_rectangles_intersect(int64_t n, const double *qpos_r1_dev, const double *qpos_r2_dev, const double *size_r1_dev,
+                                   const double *size_r2_dev, uint8_t *out_dev, void *hip_stream) {
+    if (n == 0) return GPR_OK;
+    if (n < 0 || !qpos_r1_dev || !qpos_r2_dev || !size_r1_dev || !size_r2_dev || !out_dev)
+        return fail(nullptr, GPR_E_INVALID, "gpr_check_rectangles_intersect: bad argument");
+    hipError_t he = launch_rects(n, qpos_r1_dev, qpos_r2_dev, size_r1_dev, size_r2_dev, out_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(nullptr, he, "rectangles kernel launch");
+}
+
+int gpr_ensure_max_dyn_val(int64_t n, const double *cur_dev, const double *max_value_dev, const double *deriv_dev, double cycle_time,
+                           double *out_vals_dev, double *out_derivs_dev, void *hip_stream) {
+    if (n == 0) return GPR_OK;
+    if (n < 0 || !cur_dev || !max_value_dev || !deriv_dev || !out_vals_dev || !out_derivs_dev || !(cycle_time > 0))
+        return fail(nullptr, GPR_E_INVALID, "gpr_ensure_max_dyn_val: bad argument");
+    hipError_t he = launch_clamp(n, cur_dev, max_value_dev, deriv_dev, cycle_time, out_vals_dev, out_derivs_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(nullptr, he, "clamp kernel launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,437 @@
+// gpr_device.h -- device-side building blocks of the gfx950 engine (hand-written HIP, CDNA4 only).
+//
+// Work decomposition: ONE LANE PER MOVER. An env with M movers occupies LPE = next_pow2(M) adjacent lanes of one
+// 64-wide wavefront ("env group"), so 65 536 envs x 4 movers fill 4 096 wavefronts (4 per SIMD) instead of the 1 024 an
+// env-per-lane mapping would give. State, actions and observations are row-major [E][2M] (x,y interleaved), so lane
+// (env, mover) moves one naturally aligned 8-byte (float2) or 16-byte (double2) element per array and a wavefront
+// touches one contiguous 512 B / 1 KiB span per access. Mover<->mover data (the O(M^2) pair sweep) moves through DPP
+// lane permutes inside the group, per-env decisions through one wavefront ballot. No MFMA: there is no contraction here.
+//
+// Reference citations: BE = gymnasium_planar_robotics/envs/basic_envs.py, PL = envs/planning/benchmark_planning_env.py,
+// GEO = utils/geometry_2D_utils.py, ROT = utils/rotations_utils.py of ubi-coro/gymnasium-planar-robotics.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpr {
+
+constexpr uint32_t KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4;
+constexpr int BLOCK = 256;
+
+// Scalar constants in the compute type. The host fills a float and a double copy so that a kernel reads its constants
+// straight from the kernarg segment into SGPRs (gfx950 has no scalar f64->f32 convert).
+template <typename RT> struct Cst {
+    RT dt, inv_dt, v_max, a_max, j_max, thr, sig_p, sig_v, sig_a;
+    RT inv_wx, inv_wy;
+    RT min_x, min_y, max_x, max_y, min_goal_dist, reward_success;
+    RT c_offset, c_offset_wall, tile_hx, tile_hy;
+    RT max_csum_step, max_csum_safe;  // max over mover pairs of (c_i + c_j), without / with the safety offset (BE:390,409)
+};
+
+// Everything a kernel needs, passed by value (kernarg segment).
+struct KParams {
+    int64_t E, env_id_offset;
+    int32_t M, Tx, Ty, c_shape;
+    int32_t num_cycles, max_episode_steps, autoreset, max_reset_trials, learn_jerk, noise, reset_all;
+    uint32_t seed_lo, seed_hi, tick_lo, tick_hi;
+    Cst<float> cf;
+    Cst<double> cd;
+    // device tables (one buffer per compute type): axis tables, per-tile LUT, neighbour masks, per-mover sizes
+    const void *tables;
+    uint32_t table_bytes, off_ax, off_ay, off_lut, off_nbr, off_csz, off_cx, off_cy;
+    // state
+    void *pos, *vel, *acc, *goal;
+    int32_t *elapsed;
+    const void *action;
+    const uint8_t *mask;
+    // outputs
+    void *obs, *ag, *dg, *reward;
+    uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
+    void *final_obs, *final_ag, *final_dg;
+};
+template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
+template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }
+template <> __host__ __device__ __forceinline__ const Cst<double> &cst<double>(const KParams &P) { return P.cd; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small vector + math traits
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct V2;
+template <> struct V2<float> { using type = float2; };
+template <> struct V2<double> { using type = double2; };
+
+template <typename RT> struct R2 { RT x, y; };
+
+template <typename ST, typename RT> __device__ __forceinline__ R2<RT> load2(const void *base, int64_t idx) {
+    typename V2<ST>::type v = *reinterpret_cast<const typename V2<ST>::type *>(static_cast<const ST *>(base) + idx);
+    return R2<RT>{(RT)v.x, (RT)v.y};
+}
+template <typename ST, typename RT> __device__ __forceinline__ void store2(void *base, int64_t idx, R2<RT> v) {
+    typename V2<ST>::type o;
+    o.x = (ST)v.x;
+    o.y = (ST)v.y;
+    *reinterpret_cast<typename V2<ST>::type *>(static_cast<ST *>(base) + idx) = o;
+}
+// value as it will read back from storage (float storage under double arithmetic rounds here)
+template <typename ST, typename RT> __device__ __forceinline__ RT stored(RT v) { return (RT)(ST)v; }
+
+template <typename RT> struct Math;
+template <> struct Math<float> {
+    static constexpr bool literal = false;  // throughput mode: squared-norm compares, rsqrt, reciprocal of dt
+    static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ int floor_int(float x) { return __float2int_rd(x); }
+    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+};
+template <> struct Math<double> {
+    static constexpr bool literal = true;  // parity mode: the reference's operations in the reference's order
+    static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+    static __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
+    static __device__ __forceinline__ int floor_int(double x) { return __double2int_rd(x); }
+    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RNG spec "gpr-rng-v1": counter based, 32-bit ops. key = hash(seed, tick, kind, env, mover); draw k = lowbias32(key +
+// (k+1)*golden). Mirrors oracle/gpr_oracle.c (gpro_rng_*), written independently.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rng_key(const KParams &P, uint32_t kind, int64_t env_global, uint32_t mover) {
+    uint32_t h = 0x9E3779B9U;  // the first five rounds are wave-uniform (scalar ALU)
+    h = mix32(h ^ P.seed_lo);
+    h = mix32(h ^ P.seed_hi);
+    h = mix32(h ^ P.tick_lo);
+    h = mix32(h ^ P.tick_hi);
+    h = mix32(h ^ kind);
+    h = mix32(h ^ (uint32_t)env_global);
+    h = mix32(h ^ (uint32_t)((uint64_t)env_global >> 32));
+    h = mix32(h ^ mover);
+    return h;
+}
+__device__ __forceinline__ uint32_t rng_draw(uint32_t key, uint32_t k) { return mix32(key + (k + 1u) * 0x9E3779B9U); }
+
+template <typename RT> __device__ __forceinline__ RT rng_uniform(uint32_t key, uint32_t k) {  // [0,1), 24 bits
+    return (RT)(rng_draw(key, k) >> 8) * (RT)(1.0 / 16777216.0);
+}
+template <typename RT> __device__ __forceinline__ R2<RT> rng_normal_pair(uint32_t key, uint32_t q);
+template <> __device__ __forceinline__ R2<float> rng_normal_pair<float>(uint32_t key, uint32_t q) {
+    uint32_t a = rng_draw(key, 2u * q), b = rng_draw(key, 2u * q + 1u);
+    float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1]
+    float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);         // [0,1)
+    // v_log_f32 is log2; -2 ln(u) = -2 ln2 log2(u). v_sin/v_cos take revolutions, so 2*pi*u2 needs no multiply.
+    float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    return R2<float>{rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
+}
+template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32_t key, uint32_t q) {
+    uint32_t a = rng_draw(key, 2u * q), b = rng_draw(key, 2u * q + 1u);
+    double u1 = (double)((a >> 8) + 1u) * (1.0 / 16777216.0);
+    double u2 = (double)(b >> 8) * (1.0 / 16777216.0);
+    double rad = sqrt(-2.0 * log(u1));
+    double ang = 6.283185307179586476925286766559 * u2;
+    return R2<double>{rad * cos(ang), rad * sin(ang)};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lane permutes inside an env group of LPE lanes (LPE in {1,2,4,8,16}; a group never straddles a 16-lane DPP row)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// value of lane (group_base + (mover + D) % LPE)
+template <int LPE, int D> __device__ __forceinline__ uint32_t rot_u32(uint32_t v) {
+    static_assert(D >= 1 && D < LPE, "rotation distance");
+    if constexpr (LPE == 2) {
+        return dpp_u32<0xB1>(v);  // quad_perm [1,0,3,2]
+    } else if constexpr (LPE == 4) {
+        if constexpr (D == 1) return dpp_u32<0x39>(v);  // quad_perm [1,2,3,0]
+        else if constexpr (D == 2) return dpp_u32<0x4E>(v);  // quad_perm [2,3,0,1]
+        else return dpp_u32<0x93>(v);  // quad_perm [3,0,1,2]
+    } else if constexpr (LPE == 16) {
+        return dpp_u32<0x120 + (16 - D)>(v);  // row_ror:(16-D): lane i receives lane (i + D) % 16 of its row
+    } else {  // LPE == 8: no 8-lane DPP rotate; LDS-crossbar permute (no LDS memory traffic)
+        int lane = (int)__lane_id();
+        int src = (lane & ~(LPE - 1)) | ((lane + D) & (LPE - 1));
+        return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+    }
+}
+template <int LPE, int D> __device__ __forceinline__ float rot(float v) { return __uint_as_float(rot_u32<LPE, D>(__float_as_uint(v))); }
+template <int LPE, int D> __device__ __forceinline__ double rot(double v) {
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    uint32_t lo = rot_u32<LPE, D>((uint32_t)b), hi = rot_u32<LPE, D>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// bits of the predicate for the LPE lanes of this lane's env group (bit m = mover m)
+template <int LPE> __device__ __forceinline__ uint32_t group_bits(bool pred) {
+    unsigned long long b = __ballot(pred);
+    if constexpr (LPE == 1) {
+        return (uint32_t)pred;
+    } else {
+        int base = (int)__lane_id() & ~(LPE - 1);
+        return (uint32_t)(b >> base) & ((1u << LPE) - 1u);
+    }
+}
+template <int LPE> __device__ __forceinline__ bool group_any(bool pred) { return group_bits<LPE>(pred) != 0u; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tile tables (built on the host by gpr_create, staged into LDS by every block)
+//   axis table, per tile i: {lo, hi, prev_hi, next_lo} = {c_i - h, c_i + h, c_{i-1} + h (-inf), c_{i+1} - h (+inf)}
+//     computed in f64 exactly as BE:509-512 / BE:522-526 do, then rounded to the compute type
+//   lut, per tile: 16 x 2 bits: mask_valid (BE:580-648, capped at 3) for each combination of the four "safe" compares
+//   nbr, per tile: 9 bits: which of the 3x3 neighbourhood tiles exist (bit = (dx+1)*3 + (dy+1))
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename RT> struct Tables {
+    const RT *ax, *ay;    // [T][4]
+    const uint32_t *lut;  // [Tx*Ty]
+    const uint16_t *nbr;  // [Tx*Ty]
+    const RT *csz;        // [GPR_MAX_MOVERS][2]
+    const RT *cx, *cy;    // tile centres [Tx], [Ty] (box shape only)
+};
+template <typename RT> __device__ __forceinline__ Tables<RT> make_tables(const void *base, const KParams &P) {
+    const char *b = static_cast<const char *>(base);
+    Tables<RT> T;
+    T.ax = reinterpret_cast<const RT *>(b + P.off_ax);
+    T.ay = reinterpret_cast<const RT *>(b + P.off_ay);
+    T.lut = reinterpret_cast<const uint32_t *>(b + P.off_lut);
+    T.nbr = reinterpret_cast<const uint16_t *>(b + P.off_nbr);
+    T.csz = reinterpret_cast<const RT *>(b + P.off_csz);
+    T.cx = reinterpret_cast<const RT *>(b + P.off_cx);
+    T.cy = reinterpret_cast<const RT *>(b + P.off_cy);
+    return T;
+}
+__device__ __forceinline__ void stage_tables(void *lds, const void *global, uint32_t bytes) {
+    uint32_t *d = static_cast<uint32_t *>(lds);
+    const uint32_t *s = static_cast<const uint32_t *>(global);
+    for (uint32_t i = threadIdx.x; i < bytes / 4u; i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+}
+
+// one tile, circle shape (BE:545-558 + BE:580-653): four strict compares select 2 bits of the tile's LUT
+template <typename RT>
+__device__ __forceinline__ bool tile_valid_circle(const Tables<RT> &T, int Ty, int ix, int iy, RT xlo, RT xhi, RT ylo, RT yhi, RT x,
+                                                  RT y, RT c) {
+    uint32_t bits = (uint32_t)(xlo < x - c) | ((uint32_t)(x + c < xhi) << 1) | ((uint32_t)(ylo < y - c) << 2) |
+                    ((uint32_t)(y + c < yhi) << 3);
+    uint32_t val = (T.lut[ix * Ty + iy] >> (2u * bits)) & 3u;
+    return val == 1u;
+}
+
+// qpos_is_valid for one circle (BE:459-788 with ignore_orientation). Must be called by all lanes of the wavefront
+// convergently (it votes on whether the single-tile fast path holds for everyone).
+template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KParams &P, RT x, RT y, RT c) {
+    const int Tx = P.Tx, Ty = P.Ty;
+    int ix = clampi(Math<RT>::floor_int(x * cst<RT>(P).inv_wx), 0, Tx - 1);
+    int iy = clampi(Math<RT>::floor_int(y * cst<RT>(P).inv_wy), 0, Ty - 1);
+    const RT *ex = T.ax + 4 * ix, *ey = T.ay + 4 * iy;
+    RT xlo = ex[0], xhi = ex[1], xph = ex[2], xnl = ex[3];
+    RT ylo = ey[0], yhi = ey[1], yph = ey[2], ynl = ey[3];
+    // exactly one tile contains the point, and it is the guessed one ("above a tile" is edge-inclusive, BE:508-513)
+    bool single = (xlo <= x) & (x <= xhi) & (xph < x) & (x < xnl) & (ylo <= y) & (y <= yhi) & (yph < y) & (y < ynl);
+    if (__ballot(!single) == 0ull) {
+        return tile_valid_circle(T, Ty, ix, iy, xlo, xhi, ylo, yhi, x, y, c);
+    }
+    // rare: on a tile edge (several tiles), outside the grid (none), or NaN. BE:518-540 + BE:785.
+    bool any = false, all = true, valid3 = false;
+    for (int a = ix - 1; a <= ix + 1; ++a) {
+        if (a < 0 || a >= Tx) continue;
+        const RT *fa = T.ax + 4 * a;
+        bool in_x = (fa[0] <= x) & (x <= fa[1]);
+        for (int b = iy - 1; b <= iy + 1; ++b) {
+            if (b < 0 || b >= Ty) continue;
+            const RT *fb = T.ay + 4 * b;
+            bool above = in_x & (fb[0] <= y) & (y <= fb[1]);
+            if (above) {
+                any = true;
+                valid3 |= (T.nbr[a * Ty + b] == 0x1FFu);  // centre of a complete 3x3 block, BE:530-538
+                all &= tile_valid_circle(T, Ty, a, b, fa[0], fa[1], fb[0], fb[1], x, y, c);
+            }
+        }
+    }
+    return valid3 | (any & all);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// geometry_2D_utils (GEO:9-138) + the rotation helpers it uses (ROT:248-274, ROT:414-461), for the 'box' collision shape
+// ---------------------------------------------------------------------------------------------------------------------
+// orientation determinant of [[ax,bx,cx],[ay,by,cy],[1,1,1]] (GEO:47-60 feed this matrix to numpy.linalg.det)
+template <typename RT> __device__ __forceinline__ RT det3(RT ax, RT ay, RT bx, RT by, RT cx, RT cy) {
+    return ax * (by - cy) - bx * (ay - cy) + cx * (ay - by);
+}
+template <typename RT> __device__ __forceinline__ RT absr(RT v) { return v < (RT)0 ? -v : v; }
+
+// GEO:9-69 for one pair of segments p1p2, q1q2
+template <typename RT>
+__device__ __forceinline__ bool seg_intersect(RT p1x, RT p1y, RT p2x, RT p2y, RT q1x, RT q1y, RT q2x, RT q2y) {
+    const RT eps = (RT)1e-7;
+    // GEO:30-35: a shared end point always counts
+    bool eq = ((absr(p1x - q1x) < eps) & (absr(p1y - q1y) < eps)) | ((absr(p1x - q2x) < eps) & (absr(p1y - q2y) < eps)) |
+              ((absr(p2x - q1x) < eps) & (absr(p2y - q1y) < eps)) | ((absr(p2x - q2x) < eps) & (absr(p2y - q2y) < eps));
+    // GEO:37-45: bounding boxes apart (by more than eps) in x or y
+    RT minpx = fmin(p1x, p2x), maxpx = fmax(p1x, p2x), minqx = fmin(q1x, q2x), maxqx = fmax(q1x, q2x);
+    RT minpy = fmin(p1y, p2y), maxpy = fmax(p1y, p2y), minqy = fmin(q1y, q2y), maxqy = fmax(q1y, q2y);
+    int mm = (int)((maxpx < minqx) & !(absr(maxpx - minqx) < eps)) + (int)((maxqx < minpx) & !(absr(maxqx - minpx) < eps)) +
+             (int)((maxpy < minqy) & !(absr(maxpy - minqy) < eps)) + (int)((maxqy < minpy) & !(absr(maxqy - minpy) < eps));
+    // GEO:52-64: orientation test with 1e-7 tolerance on the determinant products
+    RT pp = det3(p1x, p1y, p2x, p2y, q1x, q1y) * det3(p1x, p1y, p2x, p2y, q2x, q2y);
+    RT qq = det3(q1x, q1y, q2x, q2y, p1x, p1y) * det3(q1x, q1y, q2x, q2y, p2x, p2y);
+    bool orient = ((pp <= (RT)0) | (absr(pp) < eps)) & ((qq <= (RT)0) | (absr(qq) < eps));
+    bool res = orient;      // GEO:66
+    if (mm >= 1) res = false;  // GEO:67
+    if (eq) res = true;        // GEO:68
+    return res;
+}
+
+// GEO:72-104: the four (x,y) vertices of a yaw-rotated rectangle in the order (-,-), (-,+), (+,+), (+,-).
+// q = (w,x,y,z). The quaternion is normalised in FLOAT32 (unit_vector casts, ROT:447), the matrix is built in RT.
+template <typename RT>
+__device__ __forceinline__ void rect_vertices(RT px, RT py, RT qw, RT qx, RT qy, RT qz, RT sx, RT sy, RT *vx, RT *vy) {
+    float f0 = (float)qw, f1 = (float)qx, f2 = (float)qy, f3 = (float)qz;
+    float len = ((f0 * f0 + f1 * f1) + f2 * f2) + f3 * f3;
+    len = sqrtf(len);
+    f0 = f0 / len; f1 = f1 / len; f2 = f2 / len; f3 = f3 / len;
+    RT w = (RT)f0, x = (RT)f1, y = (RT)f2, z = (RT)f3;
+    RT Nq = ((w * w + x * x) + y * y) + z * z;  // ROT:256
+    RT s = (RT)2.0 / Nq;
+    RT X = x * s, Y = y * s, Z = z * s;
+    RT wZ = w * Z, xX = x * X, xY = x * Y, yY = y * Y, zZ = z * Z;
+    RT R00 = (RT)1.0 - (yY + zZ), R01 = xY - wZ, R10 = xY + wZ, R11 = (RT)1.0 - (xX + zZ);
+    const RT feps = sizeof(RT) == 8 ? (RT)2.220446049250313e-16 : (RT)1.1920929e-07f;
+    if (!(Nq > feps)) { R00 = (RT)1; R01 = (RT)0; R10 = (RT)0; R11 = (RT)1; }  // ROT:274
+    const RT lx[4] = {-sx, -sx, sx, sx}, ly[4] = {-sy, sy, sy, -sy};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // rot_mats @ vertices_l (GEO:102), k-ordered and unfused like NumPy's batched matmul loop; the z term is R*0
+        vx[j] = (R00 * lx[j] + R01 * ly[j]) + px;
+        vy[j] = (R10 * lx[j] + R11 * ly[j]) + py;
+    }
+}
+
+// GEO:107-138: any of the 4 x 4 edge pairs intersects (containment without edge crossing is NOT an intersection)
+template <typename RT> __device__ __forceinline__ bool rects_intersect_v(const RT *ax, const RT *ay, const RT *bx, const RT *by) {
+    bool any = false;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            any |= seg_intersect<RT>(ax[i], ay[i], ax[(i + 1) & 3], ay[(i + 1) & 3], bx[j], by[j], bx[(j + 1) & 3], by[(j + 1) & 3]);
+    return any;
+}
+
+// one tile, box shape (BE:560-572, 580-655, 657-783). v*: the mover's vertices; cx/cy: tile centre tables.
+template <typename RT>
+__device__ __forceinline__ bool tile_valid_box(const Tables<RT> &T, const RT *tcx, const RT *tcy, int Tx, int Ty, int ix, int iy, RT xlo,
+                                               RT xhi, RT ylo, RT yhi, const RT *vx, const RT *vy, RT thx, RT thy) {
+    const uint32_t lut = T.lut[ix * Ty + iy];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t bits = (uint32_t)(xlo < vx[r]) | ((uint32_t)(vx[r] < xhi) << 1) | ((uint32_t)(ylo < vy[r]) << 2) |
+                        ((uint32_t)(vy[r] < yhi) << 3);
+        sum += (lut >> (2u * bits)) & 3u;
+    }
+    bool valid = sum == 4u;  // BE:655
+    if (!valid) return false;
+    // BE:657-783: the tile and both its side neighbours towards a diagonal exist but the diagonal tile does not
+    const uint32_t n = T.nbr[ix * Ty + iy];
+    auto bit = [n](int dx, int dy) { return (n >> ((dx + 1) * 3 + (dy + 1))) & 1u; };
+    const int ddx[4] = {+1, +1, -1, -1}, ddy[4] = {-1, +1, -1, +1};  // bl, br, tl, tr in the reference's naming
+    for (int k = 0; k < 4; ++k) {
+        int dx = ddx[k], dy = ddy[k];
+        if (bit(0, 0) & bit(dx, 0) & bit(0, dy) & (bit(dx, dy) ^ 1u)) {
+            int mx = ix + dx, my = iy + dy;
+            if (mx < 0 || my < 0 || mx >= Tx || my >= Ty) continue;  // reference: mask_idx_* (BE:659,691,723,755)
+            RT bx[4], by[4];
+            rect_vertices<RT>(tcx[mx], tcy[my], (RT)1, (RT)0, (RT)0, (RT)0, thx, thy, bx, by);
+            if (rects_intersect_v<RT>(vx, vy, bx, by)) valid = false;
+        }
+    }
+    return valid;
+}
+
+// qpos_is_valid (BE:459-788), any shape, tables in any address space, no wave-level voting (one thread = one qpos)
+template <typename RT>
+__device__ __forceinline__ bool pos_valid_any(const Tables<RT> &T, const RT *tcx, const RT *tcy, const KParams &P, bool box, RT px, RT py,
+                                              RT qw, RT qx, RT qy, RT qz, RT cs0, RT cs1) {
+    const int Tx = P.Tx, Ty = P.Ty;
+    const Cst<RT> &C = cst<RT>(P);
+    RT vx[4], vy[4];
+    if (box) rect_vertices<RT>(px, py, qw, qx, qy, qz, cs0, cs1, vx, vy);  // BE:496-497
+    int gx = clampi(Math<RT>::floor_int(px * C.inv_wx), 0, Tx - 1);
+    int gy = clampi(Math<RT>::floor_int(py * C.inv_wy), 0, Ty - 1);
+    bool any = false, all = true, valid3 = false;
+    for (int a = gx - 1; a <= gx + 1; ++a) {
+        if (a < 0 || a >= Tx) continue;
+        const RT *fa = T.ax + 4 * a;
+        bool in_x = (fa[0] <= px) & (px <= fa[1]);
+        for (int b = gy - 1; b <= gy + 1; ++b) {
+            if (b < 0 || b >= Ty) continue;
+            const RT *fb = T.ay + 4 * b;
+            if (!(in_x & (fb[0] <= py) & (py <= fb[1]))) continue;  // BE:508-513
+            any = true;
+            valid3 |= (T.nbr[a * Ty + b] == 0x1FFu);
+            bool vk = box ? tile_valid_box<RT>(T, tcx, tcy, Tx, Ty, a, b, fa[0], fa[1], fb[0], fb[1], vx, vy, C.tile_hx, C.tile_hy)
+                          : tile_valid_circle<RT>(T, Ty, a, b, fa[0], fa[1], fb[0], fb[1], px, py, cs0);
+            all &= vk;
+        }
+    }
+    return valid3 | (any & all);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pair sweep (BE:392-409): every unordered pair {i,j} is seen by lane i at rotation distance d = (j-i) mod LPE <= LPE/2.
+// Returns the smallest pair distance this lane saw (squared in throughput mode), +inf if none.
+// NumPy broadcasts BE:409 to any_{a,b}(norm[b] <= csum[a]) == (min norm <= max csum); identical to the per-pair test for
+// equal radii, and reproduced as is for unequal ones.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename RT, int LPE, int D> struct PairSweep {
+    static __device__ __forceinline__ void run(RT x, RT y, int mv, int M, bool live, RT &best) {
+        if constexpr (D <= LPE / 2 && D >= 1 && LPE > 1) {
+            RT ox = rot<LPE, D>(x), oy = rot<LPE, D>(y);
+            int omv = (mv + D) & (LPE - 1);
+            RT dx = x - ox, dy = y - oy;
+            RT d2 = dx * dx + dy * dy;
+            RT m = Math<RT>::literal ? Math<RT>::sqrt_(d2) : d2;
+            bool ok = live & (omv < M);
+            best = (ok & (m < best)) ? m : best;
+            PairSweep<RT, LPE, D + 1>::run(x, y, mv, M, live, best);
+        }
+    }
+};
+template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_dist(RT x, RT y, int mv, int M, bool live) {
+    RT best = Math<RT>::inf();
+    PairSweep<RT, LPE, 1>::run(x, y, mv, M, live, best);
+    return best;
+}
+// compare a pair_min_dist result against a distance limit: <= (collision, BE:409) or < (goal spacing, PL:409)
+template <typename RT> __device__ __forceinline__ bool dist_le(RT m, RT lim) { return Math<RT>::literal ? (m <= lim) : (m <= lim * lim); }
+template <typename RT> __device__ __forceinline__ bool dist_lt(RT m, RT lim) { return Math<RT>::literal ? (m < lim) : (m < lim * lim); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ensure_max_dyn_val (PL:610-645) for one mover: returns the derivative to apply; `next` receives the next value
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename RT> __device__ __forceinline__ R2<RT> clamp_dyn(R2<RT> cur, RT max_value, R2<RT> deriv, RT dt, RT inv_dt, R2<RT> &next) {
+    RT t0 = dt * deriv.x + cur.x, t1 = dt * deriv.y + cur.y;  // PL:631
+    RT n2 = t0 * t0 + t1 * t1;
+    if constexpr (Math<RT>::literal) {
+        RT norm = sqrt(n2);  // PL:633
+        if (norm >= max_value) {  // PL:634, inclusive
+            next.x = max_value * (t0 / norm);  // PL:640-642
+            next.y = max_value * (t1 / norm);
+            return R2<RT>{(next.x - cur.x) / dt, (next.y - cur.y) / dt};  // PL:643
+        }
+        next.x = t0; next.y = t1;
+        return deriv;
+    } else {
+        bool cl = n2 >= max_value * max_value;
+        RT s = max_value * Math<RT>::rsqrt_(n2);
+        RT nx = cl ? t0 * s : t0, ny = cl ? t1 * s : t1;
+        next.x = nx; next.y = ny;
+        return R2<RT>{cl ? (nx - cur.x) * inv_dt : deriv.x, cl ? (ny - cur.y) * inv_dt : deriv.y};
+    }
+}
+
+}  // namespace gpr

@@ -1,0 +1,352 @@
+// gpr_env_kernels.hip -- fused BenchmarkPlanningEnv step / reset kernels for gfx950 (MI355X).
+//
+// One launch = one env-step of every env: clip -> num_cycles x [noisy velocity read, clamp, semi-implicit Euler, wall
+// check, pair sweep, early-out freeze] -> observation / info / reward / terminated / truncated -> auto-reset. State lives
+// in registers for the whole step; HBM is touched once per array on the way in and once on the way out.
+//
+// step():  BE:1835-1950 (template), PL:420-450 (control), PL:536-602 (obs/info), PL:459-534 (reward/terminated)
+// reset(): BE:1770-1833, PL:355-418
+#include "gpr_device.h"
+#include "gpr_host.h"
+
+namespace gpr {
+
+template <typename RT, bool NOISE> __device__ __forceinline__ R2<RT> noisy(R2<RT> v, RT sigma, uint32_t key, uint32_t q) {
+    if constexpr (NOISE) {
+        R2<RT> n = rng_normal_pair<RT>(key, q);
+        return R2<RT>{v.x + sigma * n.x, v.y + sigma * n.y};  // BE:828,841: value + N(0, sigma)
+    } else {
+        return v;
+    }
+}
+
+template <typename RT> struct Obs {
+    R2<RT> vel, ag;  // noisy velocity (observation) and noisy position (achieved_goal)
+    RT reward;
+    bool terminated, is_success;
+};
+
+// _get_obs (PL:536-573), _get_info (PL:575-602), compute_reward (PL:502-534), compute_terminated (PL:459-479)
+template <typename ST, typename RT, int LPE, bool NOISE>
+__device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint32_t q0, R2<RT> p, R2<RT> v, R2<RT> g, bool mc, bool wc,
+                                           bool live) {
+    const Cst<RT> &C = cst<RT>(P);
+    Obs<RT> o;
+    o.ag = noisy<RT, NOISE>(p, C.sig_p, key, q0);       // PL:554
+    o.vel = noisy<RT, NOISE>(v, C.sig_v, key, q0 + 1u);  // PL:555
+    // the reward is a function of the returned (stored) achieved / desired goal
+    RT dx = stored<ST, RT>(o.ag.x) - g.x, dy = stored<ST, RT>(o.ag.y) - g.y;
+    RT d2 = dx * dx + dy * dy;
+    bool reached = live & (Math<RT>::literal ? (Math<RT>::sqrt_(d2) <= C.thr) : (d2 <= C.thr * C.thr));  // PL:524, inclusive
+    int n_reached = __popc(group_bits<LPE>(reached));
+    bool coll = mc | wc;
+    RT r = -C.reward_success * (RT)coll;                      // PL:529
+    r += (RT)-1.0 * (RT)(P.M - n_reached) * (RT)(!coll);      // PL:530
+    bool all_reached = n_reached == P.M;
+    if (all_reached & !coll) r = C.reward_success;            // PL:531
+    o.reward = r;
+    o.terminated = (r == C.reward_success) | (r == -C.reward_success);  // PL:478
+    o.is_success = all_reached & !mc & !wc;                               // PL:597
+    return o;
+}
+
+// _reset_callback (PL:355-418) + the collision flags / observation of reset() (BE:1797-1831) for the env groups whose
+// `need` is set. Wave-cooperative: every lane of the wavefront must call it (it votes).
+template <typename ST, typename RT, int LPE, bool NOISE>
+__device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, bool live,
+                                               bool need, RT c, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
+    const Cst<RT> &C = cst<RT>(P);
+    const int M = P.M;
+    const RT cw_safe = (c + C.c_offset_wall) + C.c_offset;  // BE:487 with add_safety_offset=True
+    const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, (uint32_t)mvc);
+    const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
+    const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, (uint32_t)mvc);
+    const RT sx = C.max_x - C.min_x, sy = C.max_y - C.min_y;
+
+    bool pending = need;
+    R2<RT> cand = p;
+    for (int trial = 0; trial < P.max_reset_trials; ++trial) {  // PL:369-385
+        if (__ballot(pending) == 0ull) break;
+        R2<RT> cn;
+        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(ks, 2u * (uint32_t)trial));  // PL:377
+        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(ks, 2u * (uint32_t)trial + 1u));
+        bool w = live & !pos_valid_circle<RT>(T, P, cn.x, cn.y, cw_safe);                          // PL:379
+        bool hit = dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y, mv, M, live), C.max_csum_safe);  // PL:381-383
+        bool bad = group_any<LPE>(w | hit);
+        if (pending) { cand = cn; pending = bad; }
+    }
+    if (need) p = cand;
+
+    pending = need;
+    cand = g;
+    for (int trial = 0; trial < P.max_reset_trials; ++trial) {  // PL:395-413
+        if (__ballot(pending) == 0ull) break;
+        R2<RT> cn;
+        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(kg, 2u * (uint32_t)trial));  // PL:402
+        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(kg, 2u * (uint32_t)trial + 1u));
+        bool w = live & !pos_valid_circle<RT>(T, P, cn.x, cn.y, cw_safe);                              // PL:403-404
+        bool close = dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y, mv, M, live), C.min_goal_dist);  // PL:407-413, strict
+        bool bad = group_any<LPE>(w | close);
+        if (pending) { cand = cn; pending = bad; }
+    }
+    if (need) g = cand;
+
+    // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
+    R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
+    wc = group_any<LPE>(live & !pos_valid_circle<RT>(T, P, pw.x, pw.y, cw_safe));
+    R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, 1u);
+    mc = group_any<LPE>(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y, mv, M, live), C.max_csum_step));
+    return observe<ST, RT, LPE, NOISE>(P, kn, 2u, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
+}
+
+template <typename ST, typename RT>
+__device__ __forceinline__ void store_env_scalars(const KParams &P, int64_t env, int el, RT reward, bool term, bool trunc, bool succ, bool mc,
+                                                  bool wc) {
+    P.elapsed[env] = el;
+    static_cast<ST *>(P.reward)[env] = (ST)reward;
+    P.terminated[env] = (uint8_t)term;
+    P.truncated[env] = (uint8_t)trunc;
+    P.is_success[env] = (uint8_t)succ;
+    P.mover_collision[env] = (uint8_t)mc;
+    P.wall_collision[env] = (uint8_t)wc;
+}
+
+template <typename ST, typename RT, bool JERK>
+__device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag, void *dg, int64_t env, int mv, int64_t idx, R2<RT> ov,
+                                          R2<RT> acc, R2<RT> a_g, R2<RT> g, bool write_dg) {
+    if constexpr (JERK) {  // PL:560: all velocities, then all accelerations
+        int64_t base = env * (4 * (int64_t)P.M) + 2 * mv;
+        store2<ST, RT>(obs, base, ov);
+        store2<ST, RT>(obs, base + 2 * P.M, acc);
+    } else {
+        store2<ST, RT>(obs, idx, ov);
+    }
+    store2<ST, RT>(ag, idx, a_g);
+    if (write_dg) store2<ST, RT>(dg, idx, g);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// step
+// -----------------------------------------------------------------------------------------------------------------
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE>
+__global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    stage_tables(lds, P.tables, P.table_bytes);
+    const Tables<RT> T = make_tables<RT>(lds, P);
+    const Cst<RT> &C = cst<RT>(P);
+    const int M = P.M;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int mv = (int)(t & (LPE - 1));
+    const int64_t env = t / LPE;
+    const bool live_env = env < P.E;
+    const bool live = live_env & (mv < M);
+    const int64_t envc = live_env ? env : P.E - 1;  // dead lanes shadow a real env (no OOB, never stored)
+    const int mvc = mv < M ? mv : M - 1;
+    const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
+    const int64_t env_global = P.env_id_offset + envc;
+
+    R2<RT> a = load2<ST, RT>(P.action, idx);
+    R2<RT> p = load2<ST, RT>(P.pos, idx);
+    R2<RT> v = load2<ST, RT>(P.vel, idx);
+    R2<RT> g = load2<ST, RT>(P.goal, idx);
+    R2<RT> acc{(RT)0, (RT)0};
+    if constexpr (JERK) acc = load2<ST, RT>(P.acc, idx);
+    int el = P.elapsed[envc];
+    const RT c = T.csz[2 * mvc];
+    const RT cw_step = (c + C.c_offset_wall) + (RT)0 * C.c_offset;  // BE:487 with add_safety_offset=False
+
+    // BE:1871-1873: clip to the action space (PL:257-259)
+    const RT lim = JERK ? C.j_max : C.a_max;
+    a.x = fmin(fmax(a.x, -lim), lim);
+    a.y = fmin(fmax(a.y, -lim), lim);
+
+    const bool reset_first = (P.autoreset == 2) & (el < 0);  // next-step autoreset: this call only resets the env
+    bool frozen = reset_first;
+    bool wc = false, mc = false;
+    uint32_t key = 0u;
+    if constexpr (NOISE) key = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)mvc);
+
+    // Throughput (float) mode integrates DISPLACEMENTS: p = p0 + dp, v = v0 + dv, act = a0 + da with dp, dv, da summed from
+    // zero inside the step. A constant velocity adds the same 1e-3-sized increment to a ~1 m position every cycle; summed
+    // directly in float that rounds the same way 2000 times per episode (measured: 1.6e-4 m drift over 4200 cycles, above the
+    // 1e-4 parity tolerance). Summed as a displacement, the large-magnitude rounding happens once per env-step.
+    // Parity (double) mode keeps the reference's v += dt*a; p += dt*v as written.
+    const R2<RT> p0 = p, v0 = v, a0 = acc;
+    R2<RT> dp{(RT)0, (RT)0}, dv{(RT)0, (RT)0}, da{(RT)0, (RT)0};
+
+    for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
+        // _mujoco_step_callback (PL:420-450)
+        const R2<RT> vn = noisy<RT, NOISE>(v, C.sig_v, key, 3u * (uint32_t)cyc);  // PL:430
+        R2<RT> qacc, inc_a{(RT)0, (RT)0};
+        if constexpr (JERK) {  // PL:432-440
+            R2<RT> acc_tmp, vnext;
+            R2<RT> j1 = clamp_dyn<RT>(acc, C.a_max, a, C.dt, C.inv_dt, acc_tmp);
+            R2<RT> acc_p = clamp_dyn<RT>(vn, C.v_max, acc_tmp, C.dt, C.inv_dt, vnext);
+            bool diff = (acc_tmp.x != acc_p.x) | (acc_tmp.y != acc_p.y);
+            R2<RT> u;
+            if constexpr (Math<RT>::literal) {
+                u.x = diff ? (acc_p.x - acc.x) / C.dt : j1.x;
+                u.y = diff ? (acc_p.y - acc.y) / C.dt : j1.y;
+            } else {
+                u.x = diff ? (acc_p.x - acc.x) * C.inv_dt : j1.x;
+                u.y = diff ? (acc_p.y - acc.y) * C.inv_dt : j1.y;
+            }
+            // mj_step with dyntype=integrator, actearly (PL:307-310): act += dt*ctrl, qacc = act_new
+            inc_a.x = C.dt * u.x;
+            inc_a.y = C.dt * u.y;
+            if constexpr (Math<RT>::literal) {
+                qacc.x = acc.x + inc_a.x; qacc.y = acc.y + inc_a.y;
+            } else {
+                qacc.x = a0.x + (da.x + inc_a.x); qacc.y = a0.y + (da.y + inc_a.y);
+            }
+        } else {  // PL:442-443; mj_step with a plain force actuator of gain = mass: qacc = ctrl
+            R2<RT> vnext;
+            qacc = clamp_dyn<RT>(vn, C.v_max, a, C.dt, C.inv_dt, vnext);
+        }
+        // MuJoCo's default (semi-implicit) Euler step on a free, undamped, gravity-compensated body (BE:878-883, BE:1132):
+        // v += dt*qacc, then p += dt*v_new
+        if (!frozen) {
+            if constexpr (Math<RT>::literal) {
+                acc = qacc;
+                v.x = v.x + C.dt * qacc.x; v.y = v.y + C.dt * qacc.y;
+                p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
+            } else {
+                if constexpr (JERK) { da.x += inc_a.x; da.y += inc_a.y; }
+                acc = qacc;
+                dv.x += C.dt * qacc.x; dv.y += C.dt * qacc.y;
+                v.x = v0.x + dv.x; v.y = v0.y + dv.y;
+                dp.x += C.dt * v.x; dp.y += C.dt * v.y;
+                p.x = p0.x + dp.x; p.y = p0.y + dp.y;
+            }
+        }
+        // BE:1888-1901: wall check and mover check, each on its own noisy position read
+        const R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
+        const bool w = live & !pos_valid_circle<RT>(T, P, pw.x, pw.y, cw_step);
+        const R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, key, 3u * (uint32_t)cyc + 2u);
+        const bool hit = dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y, mv, M, live), C.max_csum_step);
+        const bool wa = group_any<LPE>(w), ma = group_any<LPE>(hit);
+        if (!frozen) { wc = wa; mc = ma; frozen = wa | ma; }  // BE:1904-1905: break, state stays at the colliding cycle
+    }
+
+    // state as it will be stored
+    p.x = stored<ST, RT>(p.x); p.y = stored<ST, RT>(p.y);
+    v.x = stored<ST, RT>(v.x); v.y = stored<ST, RT>(v.y);
+    acc.x = stored<ST, RT>(acc.x); acc.y = stored<ST, RT>(acc.y);
+
+    Obs<RT> o = observe<ST, RT, LPE, NOISE>(P, key, 3u * (uint32_t)P.num_cycles, p, v, g, mc, wc, live);
+    int el_new = reset_first ? el : el + 1;
+    bool trunc = (P.max_episode_steps > 0) & (el_new >= P.max_episode_steps);  // gymnasium TimeLimit
+    const bool done = (o.terminated | trunc) & !reset_first;
+    const bool need = live_env & (reset_first | ((P.autoreset == 1) & done));
+    bool succ = o.is_success;
+
+    if (__ballot(need) != 0ull) {
+        if ((P.autoreset == 1) & need & live) {  // same-step: the terminal observation goes to final_*
+            if (P.final_obs) store_obs<ST, RT, JERK>(P, P.final_obs, P.final_ag, P.final_dg, envc, mv, idx, o.vel, acc, o.ag, g, true);
+        }
+        R2<RT> rp = p, rg = g;
+        bool rwc, rmc;
+        Obs<RT> ro = group_reset<ST, RT, LPE, NOISE>(P, T, env_global, mv, mvc, live, need, c, rp, rg, rwc, rmc);
+        if (need) {
+            p = rp; g = rg;
+            v = R2<RT>{(RT)0, (RT)0};
+            acc = R2<RT>{(RT)0, (RT)0};
+            el_new = 0;
+            o.vel = ro.vel; o.ag = ro.ag;
+            if (reset_first) {  // the reset IS this call's result
+                o.reward = (RT)0; o.terminated = false; trunc = false;
+                wc = rwc; mc = rmc; succ = ro.is_success;
+            }
+        }
+    }
+    if ((P.autoreset == 2) & done) el_new = -1;
+
+    if (live) {
+        store2<ST, RT>(P.pos, idx, p);
+        store2<ST, RT>(P.vel, idx, v);
+        if constexpr (JERK) store2<ST, RT>(P.acc, idx, acc);
+        if (need) store2<ST, RT>(P.goal, idx, g);
+        store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, envc, mv, idx, o.vel, acc, o.ag, g, P.dg != P.goal);
+        if (mv == 0) store_env_scalars<ST, RT>(P, envc, el_new, o.reward, o.terminated, trunc, succ, mc, wc);
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// reset (explicit): BE:1770-1833 for the envs selected by mask (all when mask == NULL)
+// -----------------------------------------------------------------------------------------------------------------
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE>
+__global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    stage_tables(lds, P.tables, P.table_bytes);
+    const Tables<RT> T = make_tables<RT>(lds, P);
+    const int M = P.M;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int mv = (int)(t & (LPE - 1));
+    const int64_t env = t / LPE;
+    const bool live_env = env < P.E;
+    const bool live = live_env & (mv < M);
+    const int64_t envc = live_env ? env : P.E - 1;
+    const int mvc = mv < M ? mv : M - 1;
+    const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
+    const int64_t env_global = P.env_id_offset + envc;
+    const bool need = live_env & (P.mask ? (P.mask[envc] != 0) : true);
+    const RT c = T.csz[2 * mvc];
+    R2<RT> p = load2<ST, RT>(P.pos, idx), g = load2<ST, RT>(P.goal, idx);
+    bool wc, mc;
+    Obs<RT> o = group_reset<ST, RT, LPE, NOISE>(P, T, env_global, mv, mvc, live, need, c, p, g, wc, mc);
+    if (live & need) {
+        const R2<RT> zero{(RT)0, (RT)0};
+        store2<ST, RT>(P.pos, idx, p);
+        store2<ST, RT>(P.vel, idx, zero);
+        store2<ST, RT>(P.acc, idx, zero);
+        store2<ST, RT>(P.goal, idx, g);
+        store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, envc, mv, idx, o.vel, zero, o.ag, g, P.dg != P.goal);
+        if (mv == 0) store_env_scalars<ST, RT>(P, envc, 0, (RT)0, false, false, o.is_success, mc, wc);
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// launchers
+// -----------------------------------------------------------------------------------------------------------------
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipError_t launch_one(bool is_reset, const KParams &P, hipStream_t s) {
+    const int64_t threads = P.E * LPE;
+    const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    if (is_reset) {
+        hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE>), dim3(grid), dim3(BLOCK), P.table_bytes, s, P);
+    } else {
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE>), dim3(grid), dim3(BLOCK), P.table_bytes, s, P);
+    }
+    return hipGetLastError();
+}
+template <typename ST, typename RT, int LPE> static hipError_t launch_flags(bool is_reset, const KParams &P, hipStream_t s) {
+    const bool jerk = P.learn_jerk != 0, noise = P.noise != 0;
+    if (jerk) {
+        // Jerk mode is never run in float arithmetic: under the speed clamp the acceleration is a finite difference of
+        // velocities over dt = 1e-3 (PL:643), which turns float's 2.4e-7 velocity grid into 1e-3-sized acceleration errors
+        // that the activation integrator then carries (measured: 1.5e-2 m/s^2 after one env-step). gpr_step() routes
+        // learn_jerk + GPR_PRECISION_F32 to float storage with double arithmetic.
+        if constexpr (Math<RT>::literal) {
+            return noise ? launch_one<ST, RT, LPE, true, true>(is_reset, P, s) : launch_one<ST, RT, LPE, true, false>(is_reset, P, s);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
+    return noise ? launch_one<ST, RT, LPE, false, true>(is_reset, P, s) : launch_one<ST, RT, LPE, false, false>(is_reset, P, s);
+}
+template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s) {
+    switch (lpe) {
+        case 1: return launch_flags<ST, RT, 1>(is_reset, P, s);
+        case 2: return launch_flags<ST, RT, 2>(is_reset, P, s);
+        case 4: return launch_flags<ST, RT, 4>(is_reset, P, s);
+        case 8: return launch_flags<ST, RT, 8>(is_reset, P, s);
+        case 16: return launch_flags<ST, RT, 16>(is_reset, P, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+#ifndef GPR_ENV_TYPES
+#error "define GPR_ENV_TYPES as ST,RT (one translation unit per precision)"
+#endif
+template hipError_t launch_env_kernel<GPR_ENV_TYPES>(bool, int, const KParams &, hipStream_t);
+
+}  // namespace gpr

@@ -1,0 +1,21 @@
+// gpr_host.h -- launcher declarations shared by the translation units of libgpr_hip.so
+#pragma once
+#include "gpr_device.h"
+
+namespace gpr {
+
+// fused env kernels, one instantiation per (storage, compute) precision, each in its own translation unit
+template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s);
+
+// stand-alone f64 operators (gpr_ops_kernels.hip)
+hipError_t launch_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2, uint8_t *out, hipStream_t s);
+hipError_t launch_rect_vertices(int64_t n, const double *qpos, const double *size, double *out, hipStream_t s);
+hipError_t launch_rects(int64_t n, const double *r1, const double *r2, const double *s1, const double *s2, uint8_t *out, hipStream_t s);
+hipError_t launch_clamp(int64_t n, const double *cur, const double *maxv, const double *der, double dt, double *vals, double *ders, hipStream_t s);
+hipError_t launch_qpos_valid(const KParams &P, int64_t n, const double *qpos, const double *c_size, int add_safety, int32_t *out, hipStream_t s);
+hipError_t launch_mover_collision(const KParams &P, int64_t batch, const double *qpos, const double *c_size, int add_safety, uint8_t *out,
+                                  hipStream_t s);
+template <typename ST> hipError_t launch_reward(const KParams &P, int64_t batch, const void *ag, const void *dg, const uint8_t *mc,
+                                                const uint8_t *wc, void *reward, uint8_t *terminated, hipStream_t s);
+
+}  // namespace gpr

@@ -1,0 +1,165 @@
+// gpr_ops_kernels.hip -- the reference's stand-alone operators as f64 device kernels (one thread per item):
+// geometry_2D_utils (GEO:9-138), ensure_max_dyn_val (PL:610-645), qpos_is_valid (BE:459-788),
+// check_mover_collision (BE:355-424), batched compute_reward / compute_terminated (PL:459-534).
+// Compiled with -ffp-contract=off: every a*b+c stays two roundings, like NumPy.
+#include "gpr_device.h"
+#include "gpr_host.h"
+
+namespace gpr {
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+__global__ void __launch_bounds__(BLOCK) k_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2,
+                                                    uint8_t *out) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (uint8_t)seg_intersect<double>(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1], q1[2 * i], q1[2 * i + 1], q2[2 * i],
+                                            q2[2 * i + 1]);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_rect_vertices(int64_t n, const double *qpos, const double *size, double *out) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double *q = qpos + 7 * i;
+    double vx[4], vy[4];
+    rect_vertices<double>(q[0], q[1], q[3], q[4], q[5], q[6], size[2 * i], size[2 * i + 1], vx, vy);
+    for (int j = 0; j < 4; ++j) { out[8 * i + j] = vx[j]; out[8 * i + 4 + j] = vy[j]; }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_rects(int64_t n, const double *r1, const double *r2, const double *s1, const double *s2,
+                                                 uint8_t *out) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double *a = r1 + 7 * i, *b = r2 + 7 * i;
+    double ax[4], ay[4], bx[4], by[4];
+    rect_vertices<double>(a[0], a[1], a[3], a[4], a[5], a[6], s1[2 * i], s1[2 * i + 1], ax, ay);
+    rect_vertices<double>(b[0], b[1], b[3], b[4], b[5], b[6], s2[2 * i], s2[2 * i + 1], bx, by);
+    out[i] = (uint8_t)rects_intersect_v<double>(ax, ay, bx, by);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_clamp(int64_t n, const double *cur, const double *maxv, const double *der, double dt, double *vals,
+                                                 double *ders) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    R2<double> nx;
+    R2<double> d = clamp_dyn<double>(R2<double>{cur[2 * i], cur[2 * i + 1]}, maxv[i], R2<double>{der[2 * i], der[2 * i + 1]}, dt, 1.0 / dt, nx);
+    vals[2 * i] = nx.x; vals[2 * i + 1] = nx.y;
+    ders[2 * i] = d.x; ders[2 * i + 1] = d.y;
+}
+
+// qpos_is_valid: tables are read from global memory (L2-resident, a few KB)
+__global__ void __launch_bounds__(BLOCK) k_qpos_valid(const KParams P, int64_t n, const double *qpos, const double *c_size, int add_safety,
+                                                      int32_t *out) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Tables<double> T = make_tables<double>(P.tables, P);
+    const Cst<double> &C = P.cd;
+    const double *q = qpos + 7 * i;
+    // BE:487: c_size + offset_wall + int(add_safety_offset) * offset, left to right
+    double cs0 = (c_size[2 * i] + C.c_offset_wall) + (double)(add_safety != 0) * C.c_offset;
+    double cs1 = (c_size[2 * i + 1] + C.c_offset_wall) + (double)(add_safety != 0) * C.c_offset;
+    out[i] = (int32_t)pos_valid_any<double>(T, T.cx, T.cy, P, P.c_shape != 0, q[0], q[1], q[3], q[4], q[5], q[6], cs0, cs1);
+}
+
+// check_mover_collision: one thread per set of M movers
+__global__ void __launch_bounds__(BLOCK) k_mover_collision(const KParams P, int64_t batch, const double *qpos, const double *c_size,
+                                                           int add_safety, uint8_t *out) {
+    int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= batch) return;
+    const int M = P.M;
+    const double off = P.cd.c_offset * (double)(add_safety != 0);  // BE:390
+    const double *Q = qpos + 7 * (int64_t)M * b;
+    bool coll = false;
+    if (P.c_shape == 0) {
+        // BE:409 broadcasts (K,) <= (K,1) to (K,K): any_{a,b} norm[b] <= csum[a]  ==  min norm <= max csum
+        double min_norm = __builtin_huge_val(), max_csum = -__builtin_huge_val();
+        for (int i = 0; i < M - 1; ++i)
+            for (int j = i + 1; j < M; ++j) {
+                double dx = Q[7 * i] - Q[7 * j], dy = Q[7 * i + 1] - Q[7 * j + 1];
+                double norm = sqrt(dx * dx + dy * dy);
+                double csum = (c_size[2 * i] + off) + (c_size[2 * j] + off);
+                min_norm = norm < min_norm ? norm : min_norm;
+                max_csum = csum > max_csum ? csum : max_csum;
+            }
+        coll = min_norm <= max_csum;
+    } else {
+        for (int i = 0; i < M - 1; ++i)
+            for (int j = i + 1; j < M; ++j) {
+                double ci0 = c_size[2 * i] + off, ci1 = c_size[2 * i + 1] + off, cj0 = c_size[2 * j] + off, cj1 = c_size[2 * j + 1] + off;
+                double dx = Q[7 * i] - Q[7 * j], dy = Q[7 * i + 1] - Q[7 * j + 1];
+                double dist = sqrt(dx * dx + dy * dy);                     // BE:411
+                double ms = fmax(fmax(ci0, ci1), fmax(cj0, cj1));           // BE:412
+                if (dist <= 2 * (fabs(ms) + fabs(ms))) {                    // BE:413-414 (ord=1 norm of (ms, ms))
+                    const double *a = Q + 7 * i, *c = Q + 7 * j;
+                    double ax[4], ay[4], bx[4], by[4];
+                    rect_vertices<double>(a[0], a[1], a[3], a[4], a[5], a[6], ci0, ci1, ax, ay);
+                    rect_vertices<double>(c[0], c[1], c[3], c[4], c[5], c[6], cj0, cj1, bx, by);
+                    coll |= rects_intersect_v<double>(ax, ay, bx, by);     // BE:417-422
+                }
+            }
+    }
+    out[b] = (uint8_t)coll;
+}
+
+// compute_reward / compute_terminated on a HER batch (PL:459-534), one thread per transition
+template <typename ST> __global__ void __launch_bounds__(BLOCK) k_reward(const KParams P, int64_t batch, const ST *ag, const ST *dg,
+                                                                         const uint8_t *mcs, const uint8_t *wcs, ST *reward,
+                                                                         uint8_t *terminated) {
+    int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= batch) return;
+    const int M = P.M;
+    const double thr = P.cd.thr, rs = P.cd.reward_success;
+    int n_reached = 0;
+    for (int i = 0; i < M; ++i) {
+        double dx = (double)ag[2 * M * b + 2 * i] - (double)dg[2 * M * b + 2 * i];
+        double dy = (double)ag[2 * M * b + 2 * i + 1] - (double)dg[2 * M * b + 2 * i + 1];
+        n_reached += sqrt(dx * dx + dy * dy) <= thr;  // PL:522-525
+    }
+    bool coll = (mcs[b] != 0) | (wcs[b] != 0);
+    double r = -rs * (double)coll;
+    r += -1.0 * (double)(M - n_reached) * (double)(!coll);
+    if (n_reached == M && !coll) r = rs;
+    reward[b] = (ST)r;
+    if (terminated) terminated[b] = (uint8_t)((r == rs) | (r == -rs));
+}
+
+hipError_t launch_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2, uint8_t *out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_segments, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, p1, p2, q1, q2, out);
+    return hipGetLastError();
+}
+hipError_t launch_rect_vertices(int64_t n, const double *qpos, const double *size, double *out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_rect_vertices, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, qpos, size, out);
+    return hipGetLastError();
+}
+hipError_t launch_rects(int64_t n, const double *r1, const double *r2, const double *s1, const double *s2, uint8_t *out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_rects, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, r1, r2, s1, s2, out);
+    return hipGetLastError();
+}
+hipError_t launch_clamp(int64_t n, const double *cur, const double *maxv, const double *der, double dt, double *vals, double *ders,
+                        hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_clamp, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, cur, maxv, der, dt, vals, ders);
+    return hipGetLastError();
+}
+hipError_t launch_qpos_valid(const KParams &P, int64_t n, const double *qpos, const double *c_size, int add_safety, int32_t *out,
+                             hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_qpos_valid, dim3(grid_for(n)), dim3(BLOCK), 0, s, P, n, qpos, c_size, add_safety, out);
+    return hipGetLastError();
+}
+hipError_t launch_mover_collision(const KParams &P, int64_t batch, const double *qpos, const double *c_size, int add_safety, uint8_t *out,
+                                  hipStream_t s) {
+    if (batch > 0) hipLaunchKernelGGL(k_mover_collision, dim3(grid_for(batch)), dim3(BLOCK), 0, s, P, batch, qpos, c_size, add_safety, out);
+    return hipGetLastError();
+}
+template <typename ST> hipError_t launch_reward(const KParams &P, int64_t batch, const void *ag, const void *dg, const uint8_t *mc,
+                                                const uint8_t *wc, void *reward, uint8_t *terminated, hipStream_t s) {
+    if (batch > 0)
+        hipLaunchKernelGGL((k_reward<ST>), dim3(grid_for(batch)), dim3(BLOCK), 0, s, P, batch, static_cast<const ST *>(ag),
+                           static_cast<const ST *>(dg), mc, wc, static_cast<ST *>(reward), terminated);
+    return hipGetLastError();
+}
+template hipError_t launch_reward<float>(const KParams &, int64_t, const void *, const void *, const uint8_t *, const uint8_t *, void *, uint8_t *,
+                                         hipStream_t);
+template hipError_t launch_reward<double>(const KParams &, int64_t, const void *, const void *, const uint8_t *, const uint8_t *, void *,
+                                          uint8_t *, hipStream_t);
+
+}  // namespace gpr

@@ -1,0 +1,145 @@
+/*
+ * gpr.h -- C ABI of libgpr_hip.so, the MI355X (gfx950) engine behind the vectorised planar-robotics environments.
+ *
+ * The reference (ubi-coro/gymnasium-planar-robotics) has NO native / FFI boundary: its only interface is the Python
+ * Gymnasium class API. This header is therefore the boundary a maintainer would bind if the per-env hot path of
+ *   BasicPlanarRoboticsSingleAgentEnv.step / reset        (gymnasium_planar_robotics/envs/basic_envs.py:1770-1950)
+ *   BenchmarkPlanningEnv callbacks                          (envs/planning/benchmark_planning_env.py:355-688)
+ *   BasicPlanarRoboticsEnv collision checks                 (envs/basic_envs.py:355-788)
+ *   utils/geometry_2D_utils.py                              (:9-138)
+ * moved behind a shared library. Each entry point cites the reference interface it replaces. INTEGRATION.md shows the
+ * ctypes stub for the reference side.
+ *
+ * Conventions
+ *  - plain C types only; every *_dev pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr());
+ *    the library never allocates or frees caller-visible memory. It keeps one small device table per handle.
+ *  - every call is asynchronous on the hipStream_t passed as `void *hip_stream` (NULL = default stream).
+ *  - return value: 0 = ok, negative = error (GPR_E_*); gpr_last_error() returns a message. No exceptions, no asserts on
+ *    the device: a mover that is above no tile is reported as wall_collision = 1 (the reference asserts, BE:514).
+ *  - a handle is not thread-safe; use one handle per GPU / rank.
+ *  - "real" below = float for GPR_PRECISION_F32 and GPR_PRECISION_F32_F64ACC, double for GPR_PRECISION_F64.
+ */
+#ifndef GPR_H
+#define GPR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPR_MAX_MOVERS 16
+#define GPR_MAX_TILES 4096 /* num_tiles_x * num_tiles_y */
+
+enum {
+    GPR_OK = 0,
+    GPR_E_INVALID = -1,   /* bad argument / configuration */
+    GPR_E_HIP = -2,       /* a HIP runtime call failed */
+    GPR_E_UNBOUND = -3,   /* gpr_bind_state() has not been called */
+    GPR_E_UNSUPPORTED = -4
+};
+
+enum { GPR_SHAPE_CIRCLE = 0, GPR_SHAPE_BOX = 1 };                  /* collision_params['shape'], BE:260 */
+enum { GPR_AUTORESET_DISABLED = 0, GPR_AUTORESET_SAME_STEP = 1, GPR_AUTORESET_NEXT_STEP = 2 };
+enum {
+    GPR_PRECISION_F32 = 0,        /* float storage, float arithmetic (throughput mode; B(M) = 72 M + 17 bytes / env-step) */
+    GPR_PRECISION_F32_F64ACC = 1, /* float storage, double arithmetic inside a step */
+    GPR_PRECISION_F64 = 2         /* double storage and arithmetic (the reference's dtype; exact-decision parity mode) */
+};
+
+/* Constructor arguments of BenchmarkPlanningEnv (PL:165-185) that reach the hot path, plus the engine's own. */
+typedef struct {
+    int64_t num_envs;               /* envs owned by THIS handle (local shard) */
+    int64_t env_id_offset;          /* global id of local env 0: random streams are keyed by global id, so results do not
+                                       depend on how envs are sharded over GPUs */
+    int32_t num_movers;             /* 1..GPR_MAX_MOVERS */
+    int32_t num_tiles_x, num_tiles_y;
+    const int8_t *layout_tiles;     /* HOST, [num_tiles_x * num_tiles_y] row-major in {0,1} (PL:167, BE:195) */
+    double tile_half_size[2];       /* tile_params['size'][:2], half sizes (BE:201) */
+    const double *tile_x_centres;   /* HOST [num_tiles_x] = x_pos_tiles[:,0] of get_tile_xy_pos (BE:1292-1310); NULL: computed */
+    const double *tile_y_centres;   /* HOST [num_tiles_y]; NULL: computed */
+    int32_t c_shape;                /* GPR_SHAPE_* */
+    const double *c_size;           /* HOST [num_movers * 2]: circle radius in [2i]; box half sizes in [2i],[2i+1] (BE:261) */
+    double c_offset, c_offset_wall; /* BE:262-263 */
+    double cycle_time;              /* MuJoCo option/timestep, BE:283,1132 */
+    int32_t num_cycles;             /* PL:177 */
+    double v_max, a_max, j_max;     /* PL:179-181 */
+    int32_t learn_jerk;             /* PL:182 */
+    double threshold_pos;           /* PL:183 */
+    double std_noise[3];            /* position, velocity, acceleration (BE:184-192) */
+    int32_t max_episode_steps;      /* TimeLimit of the registered ids (gymnasium_planar_robotics/__init__.py:28); <= 0: none */
+    int32_t autoreset_mode;         /* GPR_AUTORESET_* */
+    double min_xy_pos[2], max_xy_pos[2]; /* PL:262-267 */
+    double min_goal_dist;           /* PL:270-274 */
+    int32_t max_reset_trials;       /* bound on the rejection loops of PL:369 / PL:395 */
+    int32_t precision;              /* GPR_PRECISION_* */
+} gpr_config;
+
+/* Environment state, DEVICE memory owned by the caller. Row-major [num_envs][2*num_movers] "real":
+ * (x,y) of mover 0, (x,y) of mover 1, ... -- the same ordering as the reference's achieved_goal (PL:561-569). */
+typedef struct {
+    void *pos_dev;        /* qpos[:2] of every mover */
+    void *vel_dev;        /* qvel[:2] */
+    void *acc_dev;        /* qacc[:2] == actuator activation in jerk mode (PL:305-312, 433) */
+    void *goal_dev;       /* self.goals (PL:415) */
+    int32_t *elapsed_dev; /* [num_envs] steps since reset (TimeLimit._elapsed_steps); -1 = "reset me" in next-step mode */
+} gpr_state;
+
+/* What step()/reset() return (BE:1950, BE:1833), batched. DEVICE memory owned by the caller. */
+typedef struct {
+    void *observation_dev;   /* [E][2M] (velocities) or [E][4M] (velocities then accelerations) real, PL:560-567 */
+    void *achieved_goal_dev; /* [E][2M] real, PL:569 */
+    void *desired_goal_dev;  /* [E][2M] real, PL:571; may alias gpr_state.goal_dev (then it is not rewritten) */
+    void *reward_dev;        /* [E] real, PL:502-534 */
+    uint8_t *terminated_dev, *truncated_dev;                        /* [E], PL:459-479 / TimeLimit */
+    uint8_t *is_success_dev, *mover_collision_dev, *wall_collision_dev; /* [E] info dict, PL:596-601 */
+    void *final_observation_dev, *final_achieved_goal_dev, *final_desired_goal_dev; /* nullable; same-step autoreset only */
+} gpr_step_out;
+
+typedef struct gpr_env gpr_env;
+
+/* BenchmarkPlanningEnv.__init__ (PL:165-291): validates the configuration, builds the tile tables (BE:203-221). */
+int gpr_create(const gpr_config *cfg, gpr_env **out_env);
+void gpr_destroy(gpr_env *env);
+/* message of the last failed call on this handle (env == NULL: of the last failed gpr_create on this thread) */
+const char *gpr_last_error(const gpr_env *env);
+int gpr_bind_state(gpr_env *env, const gpr_state *state);
+/* reset(seed=...) part of BE:1789-1791: re-keys every random stream and restarts the call counter */
+int gpr_seed(gpr_env *env, uint64_t seed);
+/* reset() (BE:1770-1833 + PL:355-418). mask_dev: nullable [E] bytes, non-zero = reset this env. Fills `out`
+ * (reward 0, terminated/truncated 0) for the envs it resets. */
+int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream);
+/* step(action) (BE:1835-1950 + PL:420-450 + TimeLimit). action_dev: [E][2M] real, clipped to the action space. */
+int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
+/* compute_reward / compute_terminated on HER batches (PL:459-534): achieved/desired [batch][2M] real. */
+int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, const void *desired_dev,
+                       const uint8_t *mover_collision_dev, const uint8_t *wall_collision_dev, void *reward_dev,
+                       uint8_t *terminated_dev, void *hip_stream);
+/* qpos_is_valid (BE:459-788) on n qpos [n][7] f64; c_size_dev [n][2] f64 before offsets; out [n] int32. */
+int gpr_qpos_is_valid(gpr_env *env, int64_t n, const double *qpos_dev, const double *c_size_dev, int32_t add_safety_offset,
+                      int32_t *out_dev, void *hip_stream);
+/* check_mover_collision (BE:355-424) on `batch` independent sets of num_movers qpos: qpos [batch][M][7] f64,
+ * c_size [M][2] f64 (device); out [batch] bytes. */
+int gpr_check_mover_collision(gpr_env *env, int64_t batch, const double *qpos_dev, const double *c_size_dev,
+                              int32_t add_safety_offset, uint8_t *out_dev, void *hip_stream);
+
+/* ---- stateless operators (f64, device pointers) --------------------------------------------------------------- */
+/* geometry_2D_utils.check_line_segments_intersect (GEO:9-69): p1,p2,q1,q2 [n][2]; out [n] bytes */
+int gpr_check_line_segments_intersect(int64_t n, const double *p1_dev, const double *p2_dev, const double *q1_dev,
+                                      const double *q2_dev, uint8_t *out_dev, void *hip_stream);
+/* geometry_2D_utils.get_2D_rect_vertices (GEO:72-104): qpos [n][7], size [n][2]; out [n][2][4] */
+int gpr_get_2D_rect_vertices(int64_t n, const double *qpos_dev, const double *size_dev, double *out_dev, void *hip_stream);
+/* geometry_2D_utils.check_rectangles_intersect (GEO:107-138) */
+int gpr_check_rectangles_intersect(int64_t n, const double *qpos_r1_dev, const double *qpos_r2_dev, const double *size_r1_dev,
+                                   const double *size_r2_dev, uint8_t *out_dev, void *hip_stream);
+/* BenchmarkPlanningEnv.ensure_max_dyn_val (PL:610-645), row-wise: cur/deriv [n][2], max_value [n] */
+int gpr_ensure_max_dyn_val(int64_t n, const double *cur_dev, const double *max_value_dev, const double *deriv_dev,
+                           double cycle_time, double *out_vals_dev, double *out_derivs_dev, void *hip_stream);
+
+/* library / build info: "gfx950;..." */
+const char *gpr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

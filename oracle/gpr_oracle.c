@@ -266,8 +266,8 @@ static int qpos_valid_one(const gpro_layout *lay, const double *xc, const double
             double cx = xc[ix], cy = yc[iy];
             /* BE:508-513, inclusive, independent of whether the tile exists */
             int above = (cx - hx <= qpos[0]) && (qpos[0] <= cx + hx) && (cy - hy <= qpos[1]) && (qpos[1] <= cy + hy);
-            track(margin, cx - hx, qpos[0]); track(margin, qpos[0], cx + hx);
-            track(margin, cy - hy, qpos[1]); track(margin, qpos[1], cy + hy);
+            /* (not tracked in `margin`: which of two adjacent tiles a centre is "above" does not change the verdict for a
+             * shape of positive size -- the strict edge compares below decide, and they are tracked) */
             if (!above) continue;
             any += 1;
             if (is_3x3_centre(lay, ix, iy)) valid3 = 1; /* BE:530-538 */
@@ -405,7 +405,7 @@ int32_t gpro_check_mover_collision(const gpro_layout *lay, int32_t m, const doub
 static int clamp_one(const double *cur, double max_value, const double *deriv, double dt, double *vals, double *ders, double *margin) {
     double t0 = dt * deriv[0] + cur[0], t1 = dt * deriv[1] + cur[1]; /* PL:631 */
     double norm = sqrt(t0 * t0 + t1 * t1);                           /* PL:633 */
-    track(margin, norm, max_value);
+    (void)margin; /* not a tracked decision: the clamp is continuous across norm == max_value */
     if (norm >= max_value) { /* PL:634 inclusive */
         vals[0] = max_value * (t0 / norm); /* PL:640-642 */
         vals[1] = max_value * (t1 / norm);
@@ -449,42 +449,38 @@ void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achiev
 }
 
 /* ======================================================================================================
- * Engine RNG spec "gpr-rng-v1" (engine-defined). 32-bit ops only so the HIP kernels can run the same
- * integer sequence: key -> lowbias32 absorb chain -> xoshiro128++ state; Box-Muller on 24-bit uniforms.
+ * Engine RNG spec "gpr-rng-v1" (engine-defined; the reference draws from NumPy PCG64 streams, which a GPU engine
+ * can neither reproduce nor needs to: sigma = 1e-5 is 10x below the 1e-4 parity tolerance). Counter-based, 32-bit
+ * ops only, order-independent, so the HIP kernels (one LANE per mover) and this oracle (one LOOP per env) produce the
+ * same integers:
+ *   key  h(seed, tick, kind, env, mover) = lowbias32 absorb chain
+ *   draw r(h, k) = lowbias32(h + (k+1)*0x9E3779B9)                 (murmur-style finaliser over a Weyl sequence)
+ *   normal pair q = Box-Muller on draws 2q, 2q+1 (24-bit uniforms)
  * ==================================================================================================== */
-static uint32_t mix32(uint32_t x) {
+static uint32_t mix32(uint32_t x) { /* "lowbias32" integer hash (C. Wellons) */
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
-void gpro_rng_seed(gpro_rng *r, uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t stream) {
+uint32_t gpro_rng_key(uint64_t seed, uint64_t tick, uint32_t kind, uint64_t env_id, uint32_t mover) {
     uint32_t h = 0x9E3779B9U;
     h = mix32(h ^ (uint32_t)seed);
     h = mix32(h ^ (uint32_t)(seed >> 32));
     h = mix32(h ^ (uint32_t)tick);
     h = mix32(h ^ (uint32_t)(tick >> 32));
-    h = mix32(h ^ stream);
+    h = mix32(h ^ kind);
     h = mix32(h ^ (uint32_t)env_id);
     h = mix32(h ^ (uint32_t)(env_id >> 32));
-    for (int i = 0; i < 4; ++i) r->s[i] = mix32(h + (uint32_t)(i + 1) * 0x9E3779B9U);
-    if ((r->s[0] | r->s[1] | r->s[2] | r->s[3]) == 0) r->s[0] = 1;
+    h = mix32(h ^ mover);
+    return h;
 }
 
-uint32_t gpro_rng_next(gpro_rng *r) { /* xoshiro128++ (Blackman & Vigna) */
-    uint32_t *s = r->s;
-    uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
-    uint32_t t = s[1] << 9;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl32(s[3], 11);
-    return result;
-}
+uint32_t gpro_rng_draw(uint32_t key, uint32_t k) { return mix32(key + (k + 1u) * 0x9E3779B9U); }
 
-double gpro_rng_uniform(gpro_rng *r) { return (double)(gpro_rng_next(r) >> 8) * (1.0 / 16777216.0); } /* [0,1) */
+double gpro_rng_uniform(uint32_t key, uint32_t k) { return (double)(gpro_rng_draw(key, k) >> 8) * (1.0 / 16777216.0); } /* [0,1) */
 
-void gpro_rng_normal_pair(gpro_rng *r, double *n0, double *n1) {
-    uint32_t a = gpro_rng_next(r), b = gpro_rng_next(r);
+void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1) {
+    uint32_t a = gpro_rng_draw(key, 2u * q), b = gpro_rng_draw(key, 2u * q + 1u);
     double u1 = (double)((a >> 8) + 1) * (1.0 / 16777216.0); /* (0,1] */
     double u2 = (double)(b >> 8) * (1.0 / 16777216.0);       /* [0,1) */
     double rad = sqrt(-2.0 * log(u1));
@@ -492,6 +488,8 @@ void gpro_rng_normal_pair(gpro_rng *r, double *n0, double *n1) {
     *n0 = rad * cos(ang);
     *n1 = rad * sin(ang);
 }
+
+enum { KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4 };
 
 /* ======================================================================================================
  * Vectorised BenchmarkPlanningEnv (BE:1770-1950 template + PL callbacks), one env at a time.
@@ -511,11 +509,11 @@ static void make_qpos(int M, const double *xy, double *qpos) {
     }
 }
 
-/* noisy copy of M xy pairs: one Box-Muller pair per mover (x <- n0, y <- n1) */
-static void noisy(const env_ctx *c, gpro_rng *rng, int M, const double *xy, double sigma, double *out) {
+/* noisy copy of M xy pairs: normal pair number q of each mover's stream (x <- n0, y <- n1) */
+static void noisy(const env_ctx *c, const uint32_t *keys, uint32_t q, int M, const double *xy, double sigma, double *out) {
     for (int i = 0; i < M; ++i) {
         double n0 = 0.0, n1 = 0.0;
-        if (c->noise) gpro_rng_normal_pair(rng, &n0, &n1);
+        if (c->noise) gpro_rng_normal_pair(keys[i], q, &n0, &n1);
         out[2 * i] = xy[2 * i] + sigma * n0;
         out[2 * i + 1] = xy[2 * i + 1] + sigma * n1;
     }
@@ -543,14 +541,14 @@ static int pair_any(const env_ctx *c, const double *xy, int add_safety, double *
 }
 
 /* _get_obs (PL:536-573) + _get_info (PL:575-602) + reward/terminated (PL:459-534) */
-static void observe(const env_ctx *c, gpro_rng *rng, const double *pos, const double *vel, const double *acc, const double *goal,
+static void observe(const env_ctx *c, const uint32_t *keys, uint32_t q0, const double *pos, const double *vel, const double *acc, const double *goal,
                     int mc, int wc, int64_t e, gpro_step_out *out, double *margin) {
     const gpro_env_cfg *cfg = c->cfg;
     int M = cfg->num_movers;
     int od = cfg->learn_jerk ? 4 * M : 2 * M;
     double npos[GPRO_MAX_MOVERS * 2], nvel[GPRO_MAX_MOVERS * 2];
-    noisy(c, rng, M, pos, cfg->std_noise[0], npos); /* PL:554 */
-    noisy(c, rng, M, vel, cfg->std_noise[1], nvel); /* PL:555 */
+    noisy(c, keys, q0, M, pos, cfg->std_noise[0], npos);     /* PL:554 */
+    noisy(c, keys, q0 + 1, M, vel, cfg->std_noise[1], nvel); /* PL:555 */
     for (int k = 0; k < 2 * M; ++k) {
         out->observation[od * e + k] = q32(cfg, nvel[k]);
         if (cfg->learn_jerk) out->observation[od * e + 2 * M + k] = q32(cfg, acc[k]); /* PL:558-560: no noise, after all velocities */
@@ -572,13 +570,17 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
                       double *goal, int32_t *elapsed, gpro_step_out *out, double *margin) {
     const gpro_env_cfg *cfg = c->cfg;
     int M = cfg->num_movers;
-    gpro_rng rng;
-    gpro_rng_seed(&rng, seed, (uint64_t)env_id, tick, 2u);
+    uint32_t ks[GPRO_MAX_MOVERS], kg[GPRO_MAX_MOVERS], kn[GPRO_MAX_MOVERS];
+    for (int i = 0; i < M; ++i) {
+        ks[i] = gpro_rng_key(seed, tick, KIND_RESET_START, (uint64_t)env_id, (uint32_t)i);
+        kg[i] = gpro_rng_key(seed, tick, KIND_RESET_GOAL, (uint64_t)env_id, (uint32_t)i);
+        kn[i] = gpro_rng_key(seed, tick, KIND_RESET_NOISE, (uint64_t)env_id, (uint32_t)i);
+    }
     double xy[GPRO_MAX_MOVERS * 2];
     for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PL:369-385 */
         for (int k = 0; k < 2 * M; ++k) {
             int d = k & 1;
-            double u = gpro_rng_uniform(&rng);
+            double u = gpro_rng_uniform(ks[k >> 1], 2u * (uint32_t)trial + (uint32_t)d);
             xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:377 */
         }
         int wall = wall_any(c, xy, 1, margin);  /* PL:379 add_safety_offset=True */
@@ -589,7 +591,7 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
     for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PL:395-413 */
         for (int k = 0; k < 2 * M; ++k) {
             int d = k & 1;
-            double u = gpro_rng_uniform(&rng);
+            double u = gpro_rng_uniform(kg[k >> 1], 2u * (uint32_t)trial + (uint32_t)d);
             xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:402 */
         }
         int wall = wall_any(c, xy, 1, margin); /* PL:403-404 */
@@ -608,11 +610,11 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
     for (int k = 0; k < 2 * M; ++k) { vel[k] = 0.0; acc[k] = 0.0; } /* reload_model + mj_forward: v = 0, act = 0, qacc = 0 */
     *elapsed = 0;
     double tmp[GPRO_MAX_MOVERS * 2];
-    noisy(c, &rng, M, pos, cfg->std_noise[0], tmp);
+    noisy(c, kn, 0, M, pos, cfg->std_noise[0], tmp);
     int wc = wall_any(c, tmp, 1, margin); /* BE:1799-1801 add_safety_offset=True */
-    noisy(c, &rng, M, pos, cfg->std_noise[0], tmp);
+    noisy(c, kn, 1, M, pos, cfg->std_noise[0], tmp);
     int mc = pair_any(c, tmp, 0, margin); /* BE:1803-1805 add_safety_offset=False */
-    observe(c, &rng, pos, vel, acc, goal, mc, wc, e, out, margin);
+    observe(c, kn, 2, pos, vel, acc, goal, mc, wc, e, out, margin);
     out->truncated[e] = 0;
 }
 
@@ -659,8 +661,8 @@ static void step_range(const env_ctx *c, int64_t e0, int64_t e1, uint64_t seed, 
             if (out->margin) out->margin[e] = m;
             continue;
         }
-        gpro_rng rng;
-        gpro_rng_seed(&rng, seed, (uint64_t)(env_id_offset + e), tick, 1u);
+        uint32_t keys[GPRO_MAX_MOVERS];
+        for (int i = 0; i < M; ++i) keys[i] = gpro_rng_key(seed, tick, KIND_STEP_NOISE, (uint64_t)(env_id_offset + e), (uint32_t)i);
         /* BE:1869-1873: clip to the action space (+-a_max, or +-j_max when learn_jerk; PL:257-259) */
         double lim = cfg->learn_jerk ? cfg->j_max : cfg->a_max;
         double a[GPRO_MAX_MOVERS * 2];
@@ -669,7 +671,7 @@ static void step_range(const env_ctx *c, int64_t e0, int64_t e1, uint64_t seed, 
         for (int cyc = 0; cyc < cfg->num_cycles; ++cyc) { /* BE:1879 */
             /* _mujoco_step_callback (PL:420-450) */
             double nv[GPRO_MAX_MOVERS * 2], u[GPRO_MAX_MOVERS * 2];
-            noisy(c, &rng, M, vel, cfg->std_noise[1], nv); /* PL:430 */
+            noisy(c, keys, 3u * (uint32_t)cyc, M, vel, cfg->std_noise[1], nv); /* PL:430 */
             for (int i = 0; i < M; ++i) {
                 double vals[2], ders[2];
                 if (cfg->learn_jerk) { /* PL:432-440 */
@@ -698,14 +700,14 @@ static void step_range(const env_ctx *c, int64_t e0, int64_t e1, uint64_t seed, 
                 pos[k] = pos[k] + dt * vel[k];
             }
             double np_[GPRO_MAX_MOVERS * 2];
-            noisy(c, &rng, M, pos, cfg->std_noise[0], np_);
+            noisy(c, keys, 3u * (uint32_t)cyc + 1u, M, pos, cfg->std_noise[0], np_);
             wc = wall_any(c, np_, 0, margin); /* BE:1888-1894 */
-            noisy(c, &rng, M, pos, cfg->std_noise[0], np_);
+            noisy(c, keys, 3u * (uint32_t)cyc + 2u, M, pos, cfg->std_noise[0], np_);
             mc = pair_any(c, np_, 0, margin); /* BE:1895-1901 */
             if (mc || wc) break;              /* BE:1904-1905 */
         }
         for (int k = 0; k < 2 * M; ++k) { pos[k] = q32(cfg, pos[k]); vel[k] = q32(cfg, vel[k]); acc[k] = q32(cfg, acc[k]); }
-        observe(c, &rng, pos, vel, acc, goal, mc, wc, e, out, margin);
+        observe(c, keys, 3u * (uint32_t)cfg->num_cycles, pos, vel, acc, goal, mc, wc, e, out, margin);
         elapsed_a[e] += 1;
         int trunc = cfg->max_episode_steps > 0 && elapsed_a[e] >= cfg->max_episode_steps; /* gymnasium TimeLimit */
         out->truncated[e] = (uint8_t)trunc;

@@ -93,12 +93,13 @@ void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achiev
                          const uint8_t *mover_collision, const uint8_t *wall_collision, double threshold_pos,
                          double reward_success, double *reward, uint8_t *terminated, uint8_t *is_success);
 
-/* ---- engine RNG spec "gpr-rng-v1" (engine-defined; the reference uses NumPy PCG64 streams) ------------- */
-typedef struct { uint32_t s[4]; } gpro_rng;
-void gpro_rng_seed(gpro_rng *r, uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t stream);
-uint32_t gpro_rng_next(gpro_rng *r);
-void gpro_rng_normal_pair(gpro_rng *r, double *n0, double *n1);
-double gpro_rng_uniform(gpro_rng *r);
+/* ---- engine RNG spec "gpr-rng-v1" (engine-defined, counter-based; the reference uses NumPy PCG64 streams) ----------
+ * key = hash(seed, tick, kind, env_id, mover); draw k of a key = lowbias32(key + (k+1)*0x9E3779B9);
+ * normal pair q = Box-Muller on draws 2q and 2q+1. kinds: 1 step noise, 2 reset starts, 3 reset goals, 4 reset noise. */
+uint32_t gpro_rng_key(uint64_t seed, uint64_t tick, uint32_t kind, uint64_t env_id, uint32_t mover);
+uint32_t gpro_rng_draw(uint32_t key, uint32_t k);
+double gpro_rng_uniform(uint32_t key, uint32_t k);
+void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1);
 
 /* ---- vectorised env -------------------------------------------------------------------------------------- */
 /* State layout (oracle side): [E][2M] row-major doubles for pos/vel/acc/goal, elapsed [E] int32.

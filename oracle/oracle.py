@@ -44,10 +44,6 @@ class StepOut(C.Structure):
                 ('final_desired_goal', C.c_void_p), ('margin', C.c_void_p)]
 
 
-class Rng(C.Structure):
-    _fields_ = [('s', C.c_uint32 * 4)]
-
-
 _lib = None
 
 
@@ -59,7 +55,8 @@ def lib():
         _lib.gpro_qpos_is_valid.restype = C.c_int64
         _lib.gpro_check_mover_collision.restype = C.c_int32
         _lib.gpro_tile_indices_mask.restype = C.c_int32
-        _lib.gpro_rng_next.restype = C.c_uint32
+        _lib.gpro_rng_key.restype = C.c_uint32
+        _lib.gpro_rng_draw.restype = C.c_uint32
         _lib.gpro_rng_uniform.restype = C.c_double
     return _lib
 
@@ -170,19 +167,19 @@ def compute_reward(achieved, desired, mover_collision, wall_collision, num_mover
     return rew, term.astype(bool), succ.astype(bool)
 
 
-def rng_stream(seed, env_id, tick, stream, n):
-    r = Rng()
-    lib().gpro_rng_seed(C.byref(r), C.c_uint64(seed), C.c_uint64(env_id), C.c_uint64(tick), C.c_uint32(stream))
-    return np.array([lib().gpro_rng_next(C.byref(r)) for _ in range(n)], dtype=np.uint32)
+def rng_key(seed, tick, kind, env_id, mover):
+    return int(lib().gpro_rng_key(C.c_uint64(seed), C.c_uint64(tick), C.c_uint32(kind), C.c_uint64(env_id), C.c_uint32(mover)))
 
 
-def rng_normals(seed, env_id, tick, stream, n_pairs):
-    r = Rng()
-    lib().gpro_rng_seed(C.byref(r), C.c_uint64(seed), C.c_uint64(env_id), C.c_uint64(tick), C.c_uint32(stream))
+def rng_draws(key, n):
+    return np.array([lib().gpro_rng_draw(C.c_uint32(key), C.c_uint32(k)) for k in range(n)], dtype=np.uint32)
+
+
+def rng_normals(key, n_pairs):
     out = np.zeros((n_pairs, 2)); a = C.c_double(); b = C.c_double()
-    for i in range(n_pairs):
-        lib().gpro_rng_normal_pair(C.byref(r), C.byref(a), C.byref(b))
-        out[i] = (a.value, b.value)
+    for q in range(n_pairs):
+        lib().gpro_rng_normal_pair(C.c_uint32(key), C.c_uint32(q), C.byref(a), C.byref(b))
+        out[q] = (a.value, b.value)
     return out
 
 
