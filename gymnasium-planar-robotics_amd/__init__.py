@@ -3,9 +3,9 @@ ubi-coro/gymnasium-planar-robotics (BenchmarkPlanningEnv step()/reset(), collisi
 executed by hand-written HIP kernels (gfx950) behind the C ABI of include/gpr.h. See DESIGN.md."""
 __version__ = '0.1.0'
 
-from . import _native, spaces
+from . import _native, distributed, spaces
 from .envs.basic_envs import VecBasicPlanarRoboticsEnv
 from .envs.planning.benchmark_planning_env import VecBenchmarkPlanningEnv
 from .utils import geometry_2D_utils
 
-__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'geometry_2D_utils', 'spaces', '_native']
+__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']

@@ -1,0 +1,105 @@
+"""Multi-GPU plumbing: env batches shard embarrassingly (the reference is literally one env per process), so the only
+cross-GPU traffic is ONE RCCL all-gather of the rollout tensors when a rollout buffer is flushed.
+
+One process per GPU (``python -m torch.distributed.run``), ``torch.distributed`` backend ``"nccl"`` (= RCCL on ROCm, over xGMI);
+the CPU tests drive the same code over ``gloo``. Random streams are keyed by GLOBAL env id (``env_id_offset``), so a sharded
+run reproduces the single-device run env for env.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_envs_global: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous env range [start, stop) owned by ``rank``; the first ``num_envs_global % world_size`` ranks own one more."""
+    assert 0 <= rank < world_size and num_envs_global >= world_size
+    base, rem = divmod(num_envs_global, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (as set by torch.distributed.run).
+    Returns (rank, local_rank, world_size); a single process needs no process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+@dataclass
+class _Field:
+    name: str
+    shape: tuple
+    dtype: torch.dtype
+    offset: int
+    nbytes: int
+
+
+class RolloutBuffer:
+    """[T, E_local, ...] rollout tensors of one rank, carved out of ONE byte buffer so that a flush is a single collective.
+
+    Fields: observation [T,E,obs_dim], achieved_goal / desired_goal / action [T,E,2M], reward [T,E] (float dtype), terminated /
+    truncated [T,E] (uint8). ``env.step`` can write straight into slot ``t`` (see ``slot``): no copy between the kernel and
+    the buffer. ``flush()`` all-gathers the raw bytes of every rank (equal shard sizes) and returns per-field views
+    [world, T, E_local, ...].
+    """
+
+    def __init__(self, horizon: int, num_envs_local: int, num_movers: int, obs_dim: int, dtype: torch.dtype = torch.float32,
+                 device: str | torch.device = 'cuda'):
+        self.T, self.E, self.M, self.obs_dim = int(horizon), int(num_envs_local), int(num_movers), int(obs_dim)
+        self.dtype, self.device = dtype, torch.device(device)
+        specs = [('observation', (obs_dim,), dtype), ('achieved_goal', (2 * num_movers,), dtype), ('desired_goal', (2 * num_movers,), dtype),
+                 ('action', (2 * num_movers,), dtype), ('reward', (), dtype), ('terminated', (), torch.uint8), ('truncated', (), torch.uint8)]
+        self.fields: list[_Field] = []
+        off = 0
+        for name, tail, dt in specs:
+            shape = (self.T, self.E) + tuple(tail)
+            nbytes = int(torch.empty((), dtype=dt).element_size())
+            for s in shape:
+                nbytes *= s
+            self.fields.append(_Field(name, shape, dt, off, nbytes))
+            off = (off + nbytes + 255) // 256 * 256  # keep every field 256-byte aligned
+        self.nbytes = off
+        self.storage = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.views = {f.name: self._view(self.storage, f) for f in self.fields}
+        self._gathered = None
+        self.t = 0
+
+    @staticmethod
+    def _view(storage: torch.Tensor, f: _Field, lead: tuple = ()) -> torch.Tensor:
+        flat = storage[..., f.offset:f.offset + f.nbytes]
+        return flat.view(f.dtype).reshape(lead + f.shape)
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        return self.views[name]
+
+    def slot(self, t: int) -> dict[str, torch.Tensor]:
+        """Views of time slot ``t`` (contiguous [E_local, ...] tensors a kernel can write into)."""
+        return {k: v[t] for k, v in self.views.items()}
+
+    def flush(self) -> dict[str, torch.Tensor]:
+        """Single all-gather of the whole buffer over the default process group (no-op gather for one process)."""
+        self.t = 0
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return {k: v.unsqueeze(0) for k, v in self.views.items()}
+        world = dist.get_world_size()
+        if self._gathered is None:
+            self._gathered = torch.empty(world * self.nbytes, dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(self._gathered, self.storage)
+        g = self._gathered.view(world, self.nbytes)
+        return {f.name: self._view(g, f, lead=(world,)) for f in self.fields}

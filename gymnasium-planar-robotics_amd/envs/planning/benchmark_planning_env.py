@@ -201,6 +201,31 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
             info['final_obs'] = self._final  # valid where terminated | truncated
         return self._obs_dict(), self._reward, self._terminated.view(torch.bool), self._truncated.view(torch.bool), info
 
+    # ------------------------------------------------------------------------------------------------------------
+    # zero-copy rollout collection: let the kernel write a step's outputs straight into caller-owned tensors
+    # ------------------------------------------------------------------------------------------------------------
+    def bind_outputs(self, observation: torch.Tensor, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, reward: torch.Tensor,
+                     terminated: torch.Tensor, truncated: torch.Tensor) -> _native.GprStepOut:
+        """Describe an alternative set of output tensors (e.g. slot ``t`` of a ``distributed.RolloutBuffer``) for ``step_into``.
+        The info flags and ``final_obs`` keep going to the env's own tensors."""
+        E, M = self.num_envs, self.num_movers
+        for t, shape, dt in ((observation, (E, self.obs_dim), self.dtype), (achieved_goal, (E, 2 * M), self.dtype),
+                             (desired_goal, (E, 2 * M), self.dtype), (reward, (E,), self.dtype), (terminated, (E,), torch.uint8),
+                             (truncated, (E,), torch.uint8)):
+            assert tuple(t.shape) == shape and t.dtype == dt and t.device == self.device and t.is_contiguous(), (tuple(t.shape), t.dtype)
+        o = _native.GprStepOut()
+        C.memmove(C.byref(o), C.byref(self._out), C.sizeof(o))
+        o.observation_dev, o.achieved_goal_dev, o.desired_goal_dev = observation.data_ptr(), achieved_goal.data_ptr(), desired_goal.data_ptr()
+        o.reward_dev, o.terminated_dev, o.truncated_dev = reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr()
+        return o
+
+    def step_into(self, action: torch.Tensor, out: _native.GprStepOut) -> None:
+        """``step()`` without any host-side bookkeeping: one C-ABI call, outputs land in the tensors ``out`` was bound to.
+        ``action`` must already be a contiguous (num_envs, 2*num_movers) tensor of the env's dtype on the env's device."""
+        assert action.dtype == self.dtype and action.device == self.device and action.is_contiguous()
+        assert tuple(action.shape) == (self.num_envs, 2 * self.num_movers), 'action dim != action_space dim'
+        _native.check(self._lib.gpr_step(self._handle, action.data_ptr(), C.byref(out), self._stream()), self._handle)
+
     def compute_reward(self, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, info: dict[str, torch.Tensor]) -> torch.Tensor:
         """Batched HER reward (PL:502-534). ``info`` holds 'mover_collision' and 'wall_collision' tensors of shape (batch,)."""
         return self._reward_and_terminated(achieved_goal, desired_goal, info)[0]
