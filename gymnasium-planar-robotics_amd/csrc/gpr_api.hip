@@ -19,7 +19,7 @@ thread_local std::string g_create_error;
 
 struct TableSet {
     void *dev = nullptr;
-    uint32_t bytes = 0, off_ax = 0, off_ay = 0, off_lut = 0, off_nbr = 0, off_csz = 0, off_cx = 0, off_cy = 0;
+    uint32_t bytes = 0, off_ax = 0, off_ay = 0, off_lut = 0, off_nbr = 0, off_csz = 0, off_cx = 0, off_cy = 0, off_lutp = 0;
 };
 
 }  // namespace
@@ -101,6 +101,7 @@ template <typename RT> int build_tables(gpr_env *e, TableSet &ts) {
     ts.off_csz = off; off = align16(off + (uint32_t)(GPR_MAX_MOVERS * 2 * sizeof(RT)));
     ts.off_cx = off; off = align16(off + (uint32_t)(Tx * sizeof(RT)));
     ts.off_cy = off; off = align16(off + (uint32_t)(Ty * sizeof(RT)));
+    ts.off_lutp = off; off = align16(off + (uint32_t)((Tx + 2) * (Ty + 2) * 4));
     ts.bytes = off;
     std::vector<uint8_t> blob(off, 0);
     const double inf = std::numeric_limits<double>::infinity();
@@ -121,6 +122,7 @@ template <typename RT> int build_tables(gpr_env *e, TableSet &ts) {
     for (int ix = 0; ix < Tx; ++ix)
         for (int iy = 0; iy < Ty; ++iy) {
             put<uint32_t>(blob, ts.off_lut, (size_t)ix * Ty + iy, tile_lut(*e, ix, iy));
+            put<uint32_t>(blob, ts.off_lutp, (size_t)(ix + 1) * (Ty + 2) + (iy + 1), tile_lut(*e, ix, iy));
             uint16_t n = 0;
             for (int dx = -1; dx <= 1; ++dx)
                 for (int dy = -1; dy <= 1; ++dy)
@@ -154,6 +156,8 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
             ms = s0 > ms ? s0 : ms; mf = s1 > mf ? s1 : mf;
         }
     c.max_csum_step = (RT)ms; c.max_csum_safe = (RT)mf;
+    c.gx0 = (RT)(e.xc.front() - g.tile_half_size[0]); c.gx1 = (RT)(e.xc.back() + g.tile_half_size[0]);
+    c.gy0 = (RT)(e.yc.front() - g.tile_half_size[1]); c.gy1 = (RT)(e.yc.back() + g.tile_half_size[1]);
 }
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -165,7 +169,7 @@ KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
     const TableSet &ts = (is_f64_ops || e->cfg.precision != GPR_PRECISION_F32 || e->cfg.learn_jerk) ? e->tab_f64 : e->tab_f32;
     P.tables = ts.dev; P.table_bytes = ts.bytes;
     P.off_ax = ts.off_ax; P.off_ay = ts.off_ay; P.off_lut = ts.off_lut; P.off_nbr = ts.off_nbr; P.off_csz = ts.off_csz;
-    P.off_cx = ts.off_cx; P.off_cy = ts.off_cy;
+    P.off_cx = ts.off_cx; P.off_cy = ts.off_cy; P.off_lutp = ts.off_lutp;
     P.seed_lo = (uint32_t)e->seed; P.seed_hi = (uint32_t)(e->seed >> 32);
     P.tick_lo = (uint32_t)e->tick; P.tick_hi = (uint32_t)(e->tick >> 32);
     P.pos = e->state.pos_dev; P.vel = e->state.vel_dev; P.acc = e->state.acc_dev; P.goal = e->state.goal_dev;
@@ -263,6 +267,14 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     P.num_cycles = c.num_cycles; P.max_episode_steps = c.max_episode_steps; P.autoreset = c.autoreset_mode;
     P.max_reset_trials = c.max_reset_trials; P.learn_jerk = c.learn_jerk != 0;
     P.noise = (c.std_noise[0] != 0.0) || (c.std_noise[1] != 0.0) || (c.std_noise[2] != 0.0);
+    // "full layout" shortcut of the throughput-mode wall check: every cell holds a tile and every collision circle, with all
+    // offsets added, is smaller than half a tile
+    bool full = n_tiles == c.num_tiles_x * c.num_tiles_y && c.c_shape == GPR_SHAPE_CIRCLE;
+    for (int i = 0; i < c.num_movers; ++i) {
+        const double cs = c.c_size[2 * i] + c.c_offset_wall + c.c_offset;
+        full = full && cs < c.tile_half_size[0] && cs < c.tile_half_size[1];
+    }
+    P.layout_full = full;
     fill_cst<float>(*e, P.cf);
     fill_cst<double>(*e, P.cd);
     *out_env = e;

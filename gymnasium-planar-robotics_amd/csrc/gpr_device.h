@@ -27,19 +27,20 @@ template <typename RT> struct Cst {
     RT min_x, min_y, max_x, max_y, min_goal_dist, reward_success;
     RT c_offset, c_offset_wall, tile_hx, tile_hy;
     RT max_csum_step, max_csum_safe;  // max over mover pairs of (c_i + c_j), without / with the safety offset (BE:390,409)
+    RT gx0, gx1, gy0, gy1;            // outer edges of the tile grid: lo of the first tile, hi of the last tile, per axis
 };
 
 // Everything a kernel needs, passed by value (kernarg segment).
 struct KParams {
     int64_t E, env_id_offset;
     int32_t M, Tx, Ty, c_shape;
-    int32_t num_cycles, max_episode_steps, autoreset, max_reset_trials, learn_jerk, noise, reset_all;
+    int32_t num_cycles, max_episode_steps, autoreset, max_reset_trials, learn_jerk, noise, layout_full;
     uint32_t seed_lo, seed_hi, tick_lo, tick_hi;
     Cst<float> cf;
     Cst<double> cd;
     // device tables (one buffer per compute type): axis tables, per-tile LUT, neighbour masks, per-mover sizes
     const void *tables;
-    uint32_t table_bytes, off_ax, off_ay, off_lut, off_nbr, off_csz, off_cx, off_cy;
+    uint32_t table_bytes, off_ax, off_ay, off_lut, off_nbr, off_csz, off_cx, off_cy, off_lutp;
     // state
     void *pos, *vel, *acc, *goal;
     int32_t *elapsed;
@@ -96,7 +97,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // ---------------------------------------------------------------------------------------------------------------------
 // RNG spec "gpr-rng-v1": counter based, 32-bit ops. key = hash(seed, tick, kind, env, mover); draw k = lowbias32(key +
-// (k+1)*golden). Mirrors oracle/gpr_oracle.c (gpro_rng_*), written independently.
+// (k+1)*golden); normal pair q = Box-Muller on the two 16-bit halves of draw q. Mirrors oracle/gpr_oracle.c (gpro_rng_*).
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -121,19 +122,20 @@ template <typename RT> __device__ __forceinline__ RT rng_uniform(uint32_t key, u
 }
 template <typename RT> __device__ __forceinline__ R2<RT> rng_normal_pair(uint32_t key, uint32_t q);
 template <> __device__ __forceinline__ R2<float> rng_normal_pair<float>(uint32_t key, uint32_t q) {
-    uint32_t a = rng_draw(key, 2u * q), b = rng_draw(key, 2u * q + 1u);
-    float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1]
-    float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);         // [0,1)
-    // v_log_f32 is log2; -2 ln(u) = -2 ln2 log2(u). v_sin/v_cos take revolutions, so 2*pi*u2 needs no multiply.
-    float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    // ONE 32-bit draw per pair: radius from the upper 16 bits, angle from the lower 16 (max radius 4.7 sigma).
+    const uint32_t r = rng_draw(key, q);
+    const float a = (float)((r >> 16) + 1u);  // (0, 65536] -> u1 = a * 2^-16
+    const float u2 = (float)(r & 0xFFFFu) * (1.0f / 65536.0f);
+    // v_log_f32 is log2: -2 ln(u1) = -2 ln2 (log2(a) - 16). v_sin / v_cos take revolutions, so 2*pi*u2 needs no multiply.
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * (__builtin_amdgcn_logf(a) - 16.0f));
     return R2<float>{rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
 }
 template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32_t key, uint32_t q) {
-    uint32_t a = rng_draw(key, 2u * q), b = rng_draw(key, 2u * q + 1u);
-    double u1 = (double)((a >> 8) + 1u) * (1.0 / 16777216.0);
-    double u2 = (double)(b >> 8) * (1.0 / 16777216.0);
-    double rad = sqrt(-2.0 * log(u1));
-    double ang = 6.283185307179586476925286766559 * u2;
+    const uint32_t r = rng_draw(key, q);
+    const double u1 = (double)((r >> 16) + 1u) * (1.0 / 65536.0);
+    const double u2 = (double)(r & 0xFFFFu) * (1.0 / 65536.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
     return R2<double>{rad * cos(ang), rad * sin(ang)};
 }
 
@@ -177,7 +179,26 @@ template <int LPE> __device__ __forceinline__ uint32_t group_bits(bool pred) {
         return (uint32_t)(b >> base) & ((1u << LPE) - 1u);
     }
 }
-template <int LPE> __device__ __forceinline__ bool group_any(bool pred) { return group_bits<LPE>(pred) != 0u; }
+// Per-env decisions as WAVE MASKS: one 64-bit scalar value holds one bit per lane, so "any lane of my env group" and the
+// frozen / collision bookkeeping of the 40-cycle loop are a handful of scalar-ALU instructions per wavefront instead of
+// vector instructions per lane. group_or: every bit of a group is set iff any bit of the group was set.
+template <int LPE> __device__ __forceinline__ unsigned long long group_or(unsigned long long b) {
+    if constexpr (LPE == 1) {
+        return b;
+    } else {
+        constexpr unsigned long long base = LPE == 2 ? 0x5555555555555555ull : LPE == 4 ? 0x1111111111111111ull
+                                          : LPE == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
+        unsigned long long g = b | (b >> 1);
+        if constexpr (LPE >= 4) g |= g >> 2;
+        if constexpr (LPE >= 8) g |= g >> 4;
+        if constexpr (LPE >= 16) g |= g >> 8;
+        g &= base;                                 // bit 0 of each group = OR of the group
+        return g * ((1ull << LPE) - 1ull);         // replicate it over the group (no carries: groups are LPE bits apart)
+    }
+}
+template <int LPE> __device__ __forceinline__ unsigned long long group_any_mask(bool pred) { return group_or<LPE>(__ballot(pred)); }
+__device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+template <int LPE> __device__ __forceinline__ bool group_any(bool pred) { return lane_of(group_any_mask<LPE>(pred)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // tile tables (built on the host by gpr_create, staged into LDS by every block)
@@ -189,6 +210,7 @@ template <int LPE> __device__ __forceinline__ bool group_any(bool pred) { return
 template <typename RT> struct Tables {
     const RT *ax, *ay;    // [T][4]
     const uint32_t *lut;  // [Tx*Ty]
+    const uint32_t *lutp; // [(Tx+2)*(Ty+2)]: lut with a ring of zeros ("no tile") around it, for clamped lookups
     const uint16_t *nbr;  // [Tx*Ty]
     const RT *csz;        // [GPR_MAX_MOVERS][2]
     const RT *cx, *cy;    // tile centres [Tx], [Ty] (box shape only)
@@ -203,6 +225,7 @@ template <typename RT> __device__ __forceinline__ Tables<RT> make_tables(const v
     T.csz = reinterpret_cast<const RT *>(b + P.off_csz);
     T.cx = reinterpret_cast<const RT *>(b + P.off_cx);
     T.cy = reinterpret_cast<const RT *>(b + P.off_cy);
+    T.lutp = reinterpret_cast<const uint32_t *>(b + P.off_lutp);
     return T;
 }
 __device__ __forceinline__ void stage_tables(void *lds, const void *global, uint32_t bytes) {
@@ -222,21 +245,16 @@ __device__ __forceinline__ bool tile_valid_circle(const Tables<RT> &T, int Ty, i
     return val == 1u;
 }
 
-// qpos_is_valid for one circle (BE:459-788 with ignore_orientation). Must be called by all lanes of the wavefront
-// convergently (it votes on whether the single-tile fast path holds for everyone).
-template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KParams &P, RT x, RT y, RT c) {
-    const int Tx = P.Tx, Ty = P.Ty;
-    int ix = clampi(Math<RT>::floor_int(x * cst<RT>(P).inv_wx), 0, Tx - 1);
-    int iy = clampi(Math<RT>::floor_int(y * cst<RT>(P).inv_wy), 0, Ty - 1);
-    const RT *ex = T.ax + 4 * ix, *ey = T.ay + 4 * iy;
-    RT xlo = ex[0], xhi = ex[1], xph = ex[2], xnl = ex[3];
-    RT ylo = ey[0], yhi = ey[1], yph = ey[2], ynl = ey[3];
-    // exactly one tile contains the point, and it is the guessed one ("above a tile" is edge-inclusive, BE:508-513)
-    bool single = (xlo <= x) & (x <= xhi) & (xph < x) & (x < xnl) & (ylo <= y) & (y <= yhi) & (yph < y) & (y < ynl);
-    if (__ballot(!single) == 0ull) {
-        return tile_valid_circle(T, Ty, ix, iy, xlo, xhi, ylo, yhi, x, y, c);
-    }
-    // rare: on a tile edge (several tiles), outside the grid (none), or NaN. BE:518-540 + BE:785.
+// collision size of one circle as the wall check wants it: metres, and (throughput mode) in tile widths
+template <typename RT> struct CircleSize {
+    RT c, cfx, cfy;
+};
+template <typename RT> __device__ __forceinline__ CircleSize<RT> circle_size(const KParams &P, RT c) {
+    return CircleSize<RT>{c, c * cst<RT>(P).inv_wx, c * cst<RT>(P).inv_wy};
+}
+
+// generic (any number of tiles under the centre, incl. none) form of BE:518-540 + BE:785, table edges compared literally
+template <typename RT> __device__ __forceinline__ bool pos_valid_circle_slow(const Tables<RT> &T, int Tx, int Ty, int ix, int iy, RT x, RT y, RT c) {
     bool any = false, all = true, valid3 = false;
     for (int a = ix - 1; a <= ix + 1; ++a) {
         if (a < 0 || a >= Tx) continue;
@@ -254,6 +272,51 @@ template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Ta
         }
     }
     return valid3 | (any & all);
+}
+
+// qpos_is_valid for one circle (BE:459-788 with ignore_orientation). Must be called by all lanes of the wavefront
+// convergently (it votes on whether the single-tile fast path holds for everyone).
+template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KParams &P, RT x, RT y, CircleSize<RT> cs) {
+    const int Tx = P.Tx, Ty = P.Ty;
+    if constexpr (Math<RT>::literal) {
+        // parity mode: every compare against the tile edges exactly as NumPy formed them
+        const RT c = cs.c;
+        int ix = clampi(Math<RT>::floor_int(x * cst<RT>(P).inv_wx), 0, Tx - 1);
+        int iy = clampi(Math<RT>::floor_int(y * cst<RT>(P).inv_wy), 0, Ty - 1);
+        const RT *ex = T.ax + 4 * ix, *ey = T.ay + 4 * iy;
+        RT xlo = ex[0], xhi = ex[1], xph = ex[2], xnl = ex[3];
+        RT ylo = ey[0], yhi = ey[1], yph = ey[2], ynl = ey[3];
+        // exactly one tile contains the point, and it is the guessed one ("above a tile" is edge-inclusive, BE:508-513)
+        bool single = (xlo <= x) & (x <= xhi) & (xph < x) & (x < xnl) & (ylo <= y) & (y <= yhi) & (yph < y) & (y < ynl);
+        if (__ballot(!single) == 0ull) return tile_valid_circle(T, Ty, ix, iy, xlo, xhi, ylo, yhi, x, y, c);
+        return pos_valid_circle_slow<RT>(T, Tx, Ty, ix, iy, x, y, c);  // rare: on a tile edge, outside the grid, NaN
+    } else {
+        const Cst<RT> &C = cst<RT>(P);
+        if (P.layout_full) {
+            // Every cell of the grid holds a tile and the circle is smaller than half a tile: an edge between two tiles
+            // never invalidates (BE:582-648 find the neighbour), so BE:459-788 reduces to "the circle's bounding box lies
+            // strictly inside the grid". Four compares, no table.
+            return (C.gx0 < x - cs.c) & (x + cs.c < C.gx1) & (C.gy0 < y - cs.c) & (y + cs.c < C.gy1);
+        }
+        // General layouts, in tile coordinates: fx = x / tile_width; its integer part names the tile, its fraction is the
+        // position inside it, and the four "safe" compares of BE:545-558 become frac > c/w and frac < 1 - c/w. One LDS read
+        // (the tile's LUT, from a zero-padded copy so that any position outside the grid reads "no tile"), issued early and
+        // consumed late. This shortcut is exact only while the centre is at least EPS tile widths away from every tile edge
+        // (EPS >> the float rounding of x / w, ~3e-6): then the tile named by the integer part is provably the only tile the
+        // reference would find the centre "above". Otherwise (rare) the whole wavefront re-evaluates with the literal test.
+        constexpr RT EPS = (RT)2e-5;
+        const RT fx = x * C.inv_wx, fy = y * C.inv_wy;
+        const RT flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
+        const RT frx = fx - flx, fry = fy - fly;
+        const int ix = (int)flx, iy = (int)fly;
+        const int ixc = clampi(ix, -1, Tx), iyc = clampi(iy, -1, Ty);
+        const uint32_t lut = T.lutp[__umul24((unsigned)(ixc + 1), (unsigned)(Ty + 2)) + (unsigned)(iyc + 1)];
+        const uint32_t sh = (frx > cs.cfx ? 2u : 0u) | (frx < (RT)1 - cs.cfx ? 4u : 0u) | (fry > cs.cfy ? 8u : 0u) | (fry < (RT)1 - cs.cfy ? 16u : 0u);
+        const bool inside = __builtin_fmaxf(__builtin_fabsf(frx - (RT)0.5), __builtin_fabsf(fry - (RT)0.5)) < (RT)0.5 - EPS;
+        bool valid = ((lut >> sh) & 3u) == 1u;
+        if (__ballot(!inside) != 0ull) valid = pos_valid_circle_slow<RT>(T, Tx, Ty, clampi(ix, 0, Tx - 1), clampi(iy, 0, Ty - 1), x, y, cs.c);
+        return valid;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -383,27 +446,27 @@ __device__ __forceinline__ bool pos_valid_any(const Tables<RT> &T, const RT *tcx
 
 // ---------------------------------------------------------------------------------------------------------------------
 // pair sweep (BE:392-409): every unordered pair {i,j} is seen by lane i at rotation distance d = (j-i) mod LPE <= LPE/2.
-// Returns the smallest pair distance this lane saw (squared in throughput mode), +inf if none.
+// Returns the smallest pair distance this lane saw (squared in throughput mode), +inf if none. Padding lanes of a group
+// (mover index >= M) must hold far_away() coordinates.
 // NumPy broadcasts BE:409 to any_{a,b}(norm[b] <= csum[a]) == (min norm <= max csum); identical to the per-pair test for
 // equal radii, and reproduced as is for unequal ones.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename RT, int LPE, int D> struct PairSweep {
-    static __device__ __forceinline__ void run(RT x, RT y, int mv, int M, bool live, RT &best) {
+    static __device__ __forceinline__ void run(RT x, RT y, RT &best) {
         if constexpr (D <= LPE / 2 && D >= 1 && LPE > 1) {
-            RT ox = rot<LPE, D>(x), oy = rot<LPE, D>(y);
-            int omv = (mv + D) & (LPE - 1);
-            RT dx = x - ox, dy = y - oy;
+            RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
             RT d2 = dx * dx + dy * dy;
             RT m = Math<RT>::literal ? Math<RT>::sqrt_(d2) : d2;
-            bool ok = live & (omv < M);
-            best = (ok & (m < best)) ? m : best;
-            PairSweep<RT, LPE, D + 1>::run(x, y, mv, M, live, best);
+            best = m < best ? m : best;
+            PairSweep<RT, LPE, D + 1>::run(x, y, best);
         }
     }
 };
-template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_dist(RT x, RT y, int mv, int M, bool live) {
+// Lanes that pad an env group (mover index >= M) are parked at FAR_AWAY so that no live mover ever sees them as a partner.
+template <typename RT> __device__ __forceinline__ RT far_away() { return sizeof(RT) == 8 ? (RT)1e150 : (RT)1e18f; }
+template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_dist(RT x, RT y) {
     RT best = Math<RT>::inf();
-    PairSweep<RT, LPE, 1>::run(x, y, mv, M, live, best);
+    PairSweep<RT, LPE, 1>::run(x, y, best);
     return best;
 }
 // compare a pair_min_dist result against a distance limit: <= (collision, BE:409) or < (goal spacing, PL:409)

@@ -57,7 +57,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
                                                bool need, RT c, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
-    const RT cw_safe = (c + C.c_offset_wall) + C.c_offset;  // BE:487 with add_safety_offset=True
+    const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);  // BE:487 with add_safety_offset=True
     const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, (uint32_t)mvc);
     const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
     const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, (uint32_t)mvc);
@@ -70,8 +70,9 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         R2<RT> cn;
         cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(ks, 2u * (uint32_t)trial));  // PL:377
         cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(ks, 2u * (uint32_t)trial + 1u));
+        if (mv >= M) cn.x = cn.y = far_away<RT>();
         bool w = live & !pos_valid_circle<RT>(T, P, cn.x, cn.y, cw_safe);                          // PL:379
-        bool hit = dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y, mv, M, live), C.max_csum_safe);  // PL:381-383
+        bool hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.max_csum_safe);  // PL:381-383
         bool bad = group_any<LPE>(w | hit);
         if (pending) { cand = cn; pending = bad; }
     }
@@ -84,8 +85,9 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         R2<RT> cn;
         cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(kg, 2u * (uint32_t)trial));  // PL:402
         cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(kg, 2u * (uint32_t)trial + 1u));
+        if (mv >= M) cn.x = cn.y = far_away<RT>();
         bool w = live & !pos_valid_circle<RT>(T, P, cn.x, cn.y, cw_safe);                              // PL:403-404
-        bool close = dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y, mv, M, live), C.min_goal_dist);  // PL:407-413, strict
+        bool close = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);  // PL:407-413, strict
         bool bad = group_any<LPE>(w | close);
         if (pending) { cand = cn; pending = bad; }
     }
@@ -95,7 +97,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
     wc = group_any<LPE>(live & !pos_valid_circle<RT>(T, P, pw.x, pw.y, cw_safe));
     R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, 1u);
-    mc = group_any<LPE>(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y, mv, M, live), C.max_csum_step));
+    mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
     return observe<ST, RT, LPE, NOISE>(P, kn, 2u, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
 }
 
@@ -131,8 +133,6 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE>
 __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     extern __shared__ __align__(16) unsigned char lds[];
-    stage_tables(lds, P.tables, P.table_bytes);
-    const Tables<RT> T = make_tables<RT>(lds, P);
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
     const int64_t env_global = P.env_id_offset + envc;
 
+    // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
     R2<RT> a = load2<ST, RT>(P.action, idx);
     R2<RT> p = load2<ST, RT>(P.pos, idx);
     R2<RT> v = load2<ST, RT>(P.vel, idx);
@@ -152,8 +153,13 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     R2<RT> acc{(RT)0, (RT)0};
     if constexpr (JERK) acc = load2<ST, RT>(P.acc, idx);
     int el = P.elapsed[envc];
-    const RT c = T.csz[2 * mvc];
-    const RT cw_step = (c + C.c_offset_wall) + (RT)0 * C.c_offset;  // BE:487 with add_safety_offset=False
+    if (mv >= M) { p.x = p.y = far_away<RT>(); v.x = v.y = (RT)0; a.x = a.y = (RT)0; acc.x = acc.y = (RT)0; }  // group padding
+    const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
+    // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): skip the LDS staging + barrier
+    const bool need_tables = Math<RT>::literal || !P.layout_full;
+    if (need_tables) stage_tables(lds, P.tables, P.table_bytes);
+    const Tables<RT> T = make_tables<RT>(lds, P);
+    const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);  // BE:487, add_safety_offset=False
 
     // BE:1871-1873: clip to the action space (PL:257-259)
     const RT lim = JERK ? C.j_max : C.a_max;
@@ -161,8 +167,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     a.y = fmin(fmax(a.y, -lim), lim);
 
     const bool reset_first = (P.autoreset == 2) & (el < 0);  // next-step autoreset: this call only resets the env
-    bool frozen = reset_first;
-    bool wc = false, mc = false;
+    // per-env decisions are kept as wave masks (one bit per lane, identical within an env group): scalar registers
+    unsigned long long frozen_m = __ballot(reset_first), wc_m = 0ull, mc_m = 0ull;
     uint32_t key = 0u;
     if constexpr (NOISE) key = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)mvc);
 
@@ -205,7 +211,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         }
         // MuJoCo's default (semi-implicit) Euler step on a free, undamped, gravity-compensated body (BE:878-883, BE:1132):
         // v += dt*qacc, then p += dt*v_new
-        if (!frozen) {
+        if (!lane_of(frozen_m)) {
             if constexpr (Math<RT>::literal) {
                 acc = qacc;
                 v.x = v.x + C.dt * qacc.x; v.y = v.y + C.dt * qacc.y;
@@ -223,10 +229,18 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         const R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
         const bool w = live & !pos_valid_circle<RT>(T, P, pw.x, pw.y, cw_step);
         const R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, key, 3u * (uint32_t)cyc + 2u);
-        const bool hit = dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y, mv, M, live), C.max_csum_step);
-        const bool wa = group_any<LPE>(w), ma = group_any<LPE>(hit);
-        if (!frozen) { wc = wa; mc = ma; frozen = wa | ma; }  // BE:1904-1905: break, state stays at the colliding cycle
+        const bool hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step);
+        // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle.
+        // wc_m / mc_m collect the raw per-lane hits of not-yet-frozen envs; only the freeze decision needs the per-env OR now.
+        const unsigned long long wb = __ballot(w) & ~frozen_m, mb = __ballot(hit) & ~frozen_m;
+        wc_m |= wb;
+        mc_m |= mb;
+        frozen_m |= group_or<LPE>(wb | mb);
     }
+    wc_m = group_or<LPE>(wc_m);
+    mc_m = group_or<LPE>(mc_m);
+    const bool wc_step = lane_of(wc_m), mc_step = lane_of(mc_m);
+    bool wc = wc_step, mc = mc_step;
 
     // state as it will be stored
     p.x = stored<ST, RT>(p.x); p.y = stored<ST, RT>(p.y);
@@ -277,8 +291,6 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE>
 __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     extern __shared__ __align__(16) unsigned char lds[];
-    stage_tables(lds, P.tables, P.table_bytes);
-    const Tables<RT> T = make_tables<RT>(lds, P);
     const int M = P.M;
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int mv = (int)(t & (LPE - 1));
@@ -290,8 +302,11 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
     const int64_t env_global = P.env_id_offset + envc;
     const bool need = live_env & (P.mask ? (P.mask[envc] != 0) : true);
-    const RT c = T.csz[2 * mvc];
+    const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];
     R2<RT> p = load2<ST, RT>(P.pos, idx), g = load2<ST, RT>(P.goal, idx);
+    if (mv >= M) p.x = p.y = far_away<RT>();
+    if (Math<RT>::literal || !P.layout_full) stage_tables(lds, P.tables, P.table_bytes);
+    const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
     Obs<RT> o = group_reset<ST, RT, LPE, NOISE>(P, T, env_global, mv, mvc, live, need, c, p, g, wc, mc);
     if (live & need) {

@@ -455,7 +455,7 @@ void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achiev
  * same integers:
  *   key  h(seed, tick, kind, env, mover) = lowbias32 absorb chain
  *   draw r(h, k) = lowbias32(h + (k+1)*0x9E3779B9)                 (murmur-style finaliser over a Weyl sequence)
- *   normal pair q = Box-Muller on draws 2q, 2q+1 (24-bit uniforms)
+ *   normal pair q = Box-Muller on the two 16-bit halves of draw q; uniform k = upper 24 bits of draw k
  * ==================================================================================================== */
 static uint32_t mix32(uint32_t x) { /* "lowbias32" integer hash (C. Wellons) */
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -480,9 +480,10 @@ uint32_t gpro_rng_draw(uint32_t key, uint32_t k) { return mix32(key + (k + 1u) *
 double gpro_rng_uniform(uint32_t key, uint32_t k) { return (double)(gpro_rng_draw(key, k) >> 8) * (1.0 / 16777216.0); } /* [0,1) */
 
 void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1) {
-    uint32_t a = gpro_rng_draw(key, 2u * q), b = gpro_rng_draw(key, 2u * q + 1u);
-    double u1 = (double)((a >> 8) + 1) * (1.0 / 16777216.0); /* (0,1] */
-    double u2 = (double)(b >> 8) * (1.0 / 16777216.0);       /* [0,1) */
+    /* ONE 32-bit draw per pair: radius from the upper 16 bits, angle from the lower 16 (max radius 4.7 sigma) */
+    uint32_t r = gpro_rng_draw(key, q);
+    double u1 = (double)((r >> 16) + 1u) * (1.0 / 65536.0); /* (0,1] */
+    double u2 = (double)(r & 0xFFFFu) * (1.0 / 65536.0);    /* [0,1) */
     double rad = sqrt(-2.0 * log(u1));
     double ang = 6.283185307179586476925286766559 * u2;
     *n0 = rad * cos(ang);

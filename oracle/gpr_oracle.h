@@ -95,7 +95,7 @@ void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achiev
 
 /* ---- engine RNG spec "gpr-rng-v1" (engine-defined, counter-based; the reference uses NumPy PCG64 streams) ----------
  * key = hash(seed, tick, kind, env_id, mover); draw k of a key = lowbias32(key + (k+1)*0x9E3779B9);
- * normal pair q = Box-Muller on draws 2q and 2q+1. kinds: 1 step noise, 2 reset starts, 3 reset goals, 4 reset noise. */
+ * normal pair q = Box-Muller on the two 16-bit halves of draw q; uniform k = top 24 bits of draw k. kinds: 1 step noise, 2 reset starts, 3 reset goals, 4 reset noise. */
 uint32_t gpro_rng_key(uint64_t seed, uint64_t tick, uint32_t kind, uint64_t env_id, uint32_t mover);
 uint32_t gpro_rng_draw(uint32_t key, uint32_t k);
 double gpro_rng_uniform(uint32_t key, uint32_t k);
