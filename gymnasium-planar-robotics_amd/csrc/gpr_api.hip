@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -156,6 +157,11 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
             ms = s0 > ms ? s0 : ms; mf = s1 > mf ? s1 : mf;
         }
     c.max_csum_step = (RT)ms; c.max_csum_safe = (RT)mf;
+    // noise is bounded (gpr-rng-v1 draws the Box-Muller radius from 16 bits): |reading - truth| <= sigma * R per component.
+    // The slack covers the rounding of the compared expressions (a few ulp of a coordinate of a few metres).
+    const double slack = sizeof(RT) == 8 ? 1e-12 : 1e-5;
+    c.band_p = (RT)(g.std_noise[0] * NORMAL_MAX_RADIUS * 1.001 + slack);
+    c.band_v = (RT)(g.std_noise[1] * NORMAL_MAX_RADIUS * 1.001 + slack);
     c.gx0 = (RT)(e.xc.front() - g.tile_half_size[0]); c.gx1 = (RT)(e.xc.back() + g.tile_half_size[0]);
     c.gy0 = (RT)(e.yc.front() - g.tile_half_size[1]); c.gy1 = (RT)(e.yc.back() + g.tile_half_size[1]);
 }
@@ -275,6 +281,9 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
         full = full && cs < c.tile_half_size[0] && cs < c.tile_half_size[1];
     }
     P.layout_full = full;
+    // validation switch: GPR_EAGER_NOISE=1 draws every noise sample of every cycle instead of only those that can matter
+    const char *eager = std::getenv("GPR_EAGER_NOISE");
+    P.eager_noise = eager && eager[0] == '1';
     fill_cst<float>(*e, P.cf);
     fill_cst<double>(*e, P.cd);
     *out_env = e;

@@ -28,13 +28,14 @@ template <typename RT> struct Cst {
     RT c_offset, c_offset_wall, tile_hx, tile_hy;
     RT max_csum_step, max_csum_safe;  // max over mover pairs of (c_i + c_j), without / with the safety offset (BE:390,409)
     RT gx0, gx1, gy0, gy1;            // outer edges of the tile grid: lo of the first tile, hi of the last tile, per axis
+    RT band_p, band_v;                // how far a noisy position / velocity reading can be from the true one (+ rounding slack)
 };
 
 // Everything a kernel needs, passed by value (kernarg segment).
 struct KParams {
     int64_t E, env_id_offset;
     int32_t M, Tx, Ty, c_shape;
-    int32_t num_cycles, max_episode_steps, autoreset, max_reset_trials, learn_jerk, noise, layout_full;
+    int32_t num_cycles, max_episode_steps, autoreset, max_reset_trials, learn_jerk, noise, layout_full, eager_noise;
     uint32_t seed_lo, seed_hi, tick_lo, tick_hi;
     Cst<float> cf;
     Cst<double> cd;
@@ -94,6 +95,7 @@ template <> struct Math<double> {
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+template <typename RT> __device__ __forceinline__ RT absr(RT v) { return v < (RT)0 ? -v : v; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // RNG spec "gpr-rng-v1": counter based, 32-bit ops. key = hash(seed, tick, kind, env, mover); draw k = lowbias32(key +
@@ -120,6 +122,8 @@ __device__ __forceinline__ uint32_t rng_draw(uint32_t key, uint32_t k) { return 
 template <typename RT> __device__ __forceinline__ RT rng_uniform(uint32_t key, uint32_t k) {  // [0,1), 24 bits
     return (RT)(rng_draw(key, k) >> 8) * (RT)(1.0 / 16777216.0);
 }
+// Box-Muller on a 16-bit uniform never returns a radius above sqrt(-2 ln 2^-16): each component of a normal pair is bounded.
+constexpr double NORMAL_MAX_RADIUS = 4.709640090061899;  // sqrt(32 ln 2)
 template <typename RT> __device__ __forceinline__ R2<RT> rng_normal_pair(uint32_t key, uint32_t q);
 template <> __device__ __forceinline__ R2<float> rng_normal_pair<float>(uint32_t key, uint32_t q) {
     // ONE 32-bit draw per pair: radius from the upper 16 bits, angle from the lower 16 (max radius 4.7 sigma).
@@ -247,10 +251,12 @@ __device__ __forceinline__ bool tile_valid_circle(const Tables<RT> &T, int Ty, i
 
 // collision size of one circle as the wall check wants it: metres, and (throughput mode) in tile widths
 template <typename RT> struct CircleSize {
-    RT c, cfx, cfy;
+    RT c, cfx, cfy;  // radius in metres and in tile widths
+    RT wx, wy;       // full-grid test: how far the centre may be from the grid centre, per axis
 };
 template <typename RT> __device__ __forceinline__ CircleSize<RT> circle_size(const KParams &P, RT c) {
-    return CircleSize<RT>{c, c * cst<RT>(P).inv_wx, c * cst<RT>(P).inv_wy};
+    const Cst<RT> &C = cst<RT>(P);
+    return CircleSize<RT>{c, c * C.inv_wx, c * C.inv_wy, (RT)0.5 * (C.gx1 - C.gx0) - c, (RT)0.5 * (C.gy1 - C.gy0) - c};
 }
 
 // generic (any number of tiles under the centre, incl. none) form of BE:518-540 + BE:785, table edges compared literally
@@ -276,7 +282,11 @@ template <typename RT> __device__ __forceinline__ bool pos_valid_circle_slow(con
 
 // qpos_is_valid for one circle (BE:459-788 with ignore_orientation). Must be called by all lanes of the wavefront
 // convergently (it votes on whether the single-tile fast path holds for everyone).
-template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KParams &P, RT x, RT y, CircleSize<RT> cs) {
+// UNC: also report in `uncertain` whether a displacement of the centre by up to `band` in x and in y could change the
+// verdict (or the path taken to it). Conservative: false guarantees that every such displacement yields the same verdict.
+template <typename RT, bool FULL, bool UNC = false>
+__device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KParams &P, RT x, RT y, CircleSize<RT> cs, RT band = (RT)0,
+                                                 bool *uncertain = nullptr) {
     const int Tx = P.Tx, Ty = P.Ty;
     if constexpr (Math<RT>::literal) {
         // parity mode: every compare against the tile edges exactly as NumPy formed them
@@ -288,15 +298,22 @@ template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Ta
         RT ylo = ey[0], yhi = ey[1], yph = ey[2], ynl = ey[3];
         // exactly one tile contains the point, and it is the guessed one ("above a tile" is edge-inclusive, BE:508-513)
         bool single = (xlo <= x) & (x <= xhi) & (xph < x) & (x < xnl) & (ylo <= y) & (y <= yhi) & (yph < y) & (y < ynl);
+        if constexpr (UNC) {
+            *uncertain = !single | (x - xlo <= band) | (xhi - x <= band) | (y - ylo <= band) | (yhi - y <= band) |
+                         (absr((x - c) - xlo) <= band) | (absr(xhi - (x + c)) <= band) | (absr((y - c) - ylo) <= band) |
+                         (absr(yhi - (y + c)) <= band);
+        }
         if (__ballot(!single) == 0ull) return tile_valid_circle(T, Ty, ix, iy, xlo, xhi, ylo, yhi, x, y, c);
         return pos_valid_circle_slow<RT>(T, Tx, Ty, ix, iy, x, y, c);  // rare: on a tile edge, outside the grid, NaN
     } else {
         const Cst<RT> &C = cst<RT>(P);
-        if (P.layout_full) {
+        if constexpr (FULL) {
             // Every cell of the grid holds a tile and the circle is smaller than half a tile: an edge between two tiles
             // never invalidates (BE:582-648 find the neighbour), so BE:459-788 reduces to "the circle's bounding box lies
-            // strictly inside the grid". Four compares, no table.
-            return (C.gx0 < x - cs.c) & (x + cs.c < C.gx1) & (C.gy0 < y - cs.c) & (y + cs.c < C.gy1);
+            // strictly inside the grid": the smaller of the two axis margins is positive. No table.
+            const RT m = __builtin_fminf(cs.wx - __builtin_fabsf(x - (RT)0.5 * (C.gx0 + C.gx1)), cs.wy - __builtin_fabsf(y - (RT)0.5 * (C.gy0 + C.gy1)));
+            if constexpr (UNC) *uncertain = !(__builtin_fabsf(m) > band);
+            return m > (RT)0;
         }
         // General layouts, in tile coordinates: fx = x / tile_width; its integer part names the tile, its fraction is the
         // position inside it, and the four "safe" compares of BE:545-558 become frac > c/w and frac < 1 - c/w. One LDS read
@@ -312,7 +329,13 @@ template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Ta
         const int ixc = clampi(ix, -1, Tx), iyc = clampi(iy, -1, Ty);
         const uint32_t lut = T.lutp[__umul24((unsigned)(ixc + 1), (unsigned)(Ty + 2)) + (unsigned)(iyc + 1)];
         const uint32_t sh = (frx > cs.cfx ? 2u : 0u) | (frx < (RT)1 - cs.cfx ? 4u : 0u) | (fry > cs.cfy ? 8u : 0u) | (fry < (RT)1 - cs.cfy ? 16u : 0u);
-        const bool inside = __builtin_fmaxf(__builtin_fabsf(frx - (RT)0.5), __builtin_fabsf(fry - (RT)0.5)) < (RT)0.5 - EPS;
+        const RT edge = __builtin_fmaxf(__builtin_fabsf(frx - (RT)0.5), __builtin_fabsf(fry - (RT)0.5));  // 0.5 = on a tile edge
+        const bool inside = edge < (RT)0.5 - EPS;
+        if constexpr (UNC) {
+            const RT bx = band * C.inv_wx, by = band * C.inv_wy, bt = __builtin_fmaxf(bx, by);
+            *uncertain = !(edge < (RT)0.5 - EPS - bt) | (__builtin_fabsf(frx - cs.cfx) <= bx) | (__builtin_fabsf(frx - ((RT)1 - cs.cfx)) <= bx) |
+                         (__builtin_fabsf(fry - cs.cfy) <= by) | (__builtin_fabsf(fry - ((RT)1 - cs.cfy)) <= by);
+        }
         bool valid = ((lut >> sh) & 3u) == 1u;
         if (__ballot(!inside) != 0ull) valid = pos_valid_circle_slow<RT>(T, Tx, Ty, clampi(ix, 0, Tx - 1), clampi(iy, 0, Ty - 1), x, y, cs.c);
         return valid;
@@ -326,7 +349,6 @@ template <typename RT> __device__ __forceinline__ bool pos_valid_circle(const Ta
 template <typename RT> __device__ __forceinline__ RT det3(RT ax, RT ay, RT bx, RT by, RT cx, RT cy) {
     return ax * (by - cy) - bx * (ay - cy) + cx * (ay - by);
 }
-template <typename RT> __device__ __forceinline__ RT absr(RT v) { return v < (RT)0 ? -v : v; }
 
 // GEO:9-69 for one pair of segments p1p2, q1q2
 template <typename RT>

@@ -52,7 +52,7 @@ __device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint3
 
 // _reset_callback (PL:355-418) + the collision flags / observation of reset() (BE:1797-1831) for the env groups whose
 // `need` is set. Wave-cooperative: every lane of the wavefront must call it (it votes).
-template <typename ST, typename RT, int LPE, bool NOISE>
+template <typename ST, typename RT, int LPE, bool NOISE, bool FULL>
 __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, bool live,
                                                bool need, RT c, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
     const Cst<RT> &C = cst<RT>(P);
@@ -71,7 +71,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(ks, 2u * (uint32_t)trial));  // PL:377
         cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(ks, 2u * (uint32_t)trial + 1u));
         if (mv >= M) cn.x = cn.y = far_away<RT>();
-        bool w = live & !pos_valid_circle<RT>(T, P, cn.x, cn.y, cw_safe);                          // PL:379
+        bool w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                          // PL:379
         bool hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.max_csum_safe);  // PL:381-383
         bool bad = group_any<LPE>(w | hit);
         if (pending) { cand = cn; pending = bad; }
@@ -86,7 +86,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(kg, 2u * (uint32_t)trial));  // PL:402
         cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(kg, 2u * (uint32_t)trial + 1u));
         if (mv >= M) cn.x = cn.y = far_away<RT>();
-        bool w = live & !pos_valid_circle<RT>(T, P, cn.x, cn.y, cw_safe);                              // PL:403-404
+        bool w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                              // PL:403-404
         bool close = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);  // PL:407-413, strict
         bool bad = group_any<LPE>(w | close);
         if (pending) { cand = cn; pending = bad; }
@@ -95,7 +95,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
 
     // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
     R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
-    wc = group_any<LPE>(live & !pos_valid_circle<RT>(T, P, pw.x, pw.y, cw_safe));
+    wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
     R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, 1u);
     mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
     return observe<ST, RT, LPE, NOISE>(P, kn, 2u, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
@@ -130,7 +130,7 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 // -----------------------------------------------------------------------------------------------------------------
 // step
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE>
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL>
 __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
@@ -155,9 +155,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     int el = P.elapsed[envc];
     if (mv >= M) { p.x = p.y = far_away<RT>(); v.x = v.y = (RT)0; a.x = a.y = (RT)0; acc.x = acc.y = (RT)0; }  // group padding
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
-    // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): skip the LDS staging + barrier
-    const bool need_tables = Math<RT>::literal || !P.layout_full;
-    if (need_tables) stage_tables(lds, P.tables, P.table_bytes);
+    // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
+    if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);  // BE:487, add_safety_offset=False
 
@@ -172,64 +171,106 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     uint32_t key = 0u;
     if constexpr (NOISE) key = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)mvc);
 
-    // Throughput (float) mode integrates DISPLACEMENTS: p = p0 + dp, v = v0 + dv, act = a0 + da with dp, dv, da summed from
-    // zero inside the step. A constant velocity adds the same 1e-3-sized increment to a ~1 m position every cycle; summed
+    // Throughput (float) mode integrates DISPLACEMENTS: p = p0 + dp, v = v0 + dv with dp, dv summed from zero inside the
+    // step (jerk mode never runs in float, see launch_flags). A constant velocity adds the same 1e-3-sized increment to a ~1 m position every cycle; summed
     // directly in float that rounds the same way 2000 times per episode (measured: 1.6e-4 m drift over 4200 cycles, above the
     // 1e-4 parity tolerance). Summed as a displacement, the large-magnitude rounding happens once per env-step.
     // Parity (double) mode keeps the reference's v += dt*a; p += dt*v as written.
-    const R2<RT> p0 = p, v0 = v, a0 = acc;
-    R2<RT> dp{(RT)0, (RT)0}, dv{(RT)0, (RT)0}, da{(RT)0, (RT)0};
+    const R2<RT> p0 = p, v0 = v;
+    R2<RT> dp{(RT)0, (RT)0}, dv{(RT)0, (RT)0};
+
+    // LAZY NOISE. The reference perturbs three readings per mover per cycle (velocity for the clamp, position for the wall
+    // check, position again for the mover check: PL:430, BE:1888-1901). A reading can differ from the truth by at most
+    // band = sigma * NORMAL_MAX_RADIUS, so whenever the noise-free quantity is further than `band` from every threshold it is
+    // compared with, the outcome is the same for every possible draw and the draw is skipped -- results are bit-identical to
+    // drawing always (GPR_EAGER_NOISE=1 does that; tests compare the two). The branch is per wavefront: one uncertain lane
+    // makes all 64 draw.
+    const bool eager = P.eager_noise != 0;
+    const RT band_pair = (RT)2 * C.band_p;  // two movers, each off by up to band_p
+    const R2<RT> dta{C.dt * a.x, C.dt * a.y};
+    const RT vlim = C.v_max - C.band_v, vlim2 = vlim > (RT)0 ? vlim * vlim : (RT)-1;
+    // the mover check is uncertain while |dist - thr| <= band_pair; on squared distances: |d2 - thr^2| <= 2 thr band + band^2
+    const RT pair_thr = Math<RT>::literal ? C.max_csum_step : C.max_csum_step * C.max_csum_step;
+    const RT pair_band = Math<RT>::literal ? band_pair : (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
 
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
-        // _mujoco_step_callback (PL:420-450)
-        const R2<RT> vn = noisy<RT, NOISE>(v, C.sig_v, key, 3u * (uint32_t)cyc);  // PL:430
-        R2<RT> qacc, inc_a{(RT)0, (RT)0};
-        if constexpr (JERK) {  // PL:432-440
-            R2<RT> acc_tmp, vnext;
-            R2<RT> j1 = clamp_dyn<RT>(acc, C.a_max, a, C.dt, C.inv_dt, acc_tmp);
-            R2<RT> acc_p = clamp_dyn<RT>(vn, C.v_max, acc_tmp, C.dt, C.inv_dt, vnext);
-            bool diff = (acc_tmp.x != acc_p.x) | (acc_tmp.y != acc_p.y);
-            R2<RT> u;
-            if constexpr (Math<RT>::literal) {
+        // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882)
+        if constexpr (Math<RT>::literal) {
+            R2<RT> qacc, acc_tmp = a, j1 = a;
+            if constexpr (JERK) j1 = clamp_dyn<RT>(acc, C.a_max, a, C.dt, C.inv_dt, acc_tmp);  // PL:434-436 (no noise on qacc, PL:433)
+            R2<RT> vn = v;
+            if constexpr (NOISE) {
+                // the velocity reading only matters if the speed clamp can fire (PL:634): |v + dt*a| within band_v of v_max
+                const RT t0 = v.x + C.dt * acc_tmp.x, t1 = v.y + C.dt * acc_tmp.y;
+                const RT lim = C.v_max - C.band_v;
+                const bool need = !(t0 * t0 + t1 * t1 < lim * lim) | (lim <= (RT)0);
+                if (eager | (__ballot(need) != 0ull)) vn = noisy<RT, true>(v, C.sig_v, key, 3u * (uint32_t)cyc);  // PL:430
+            }
+            if constexpr (JERK) {  // PL:437-440
+                R2<RT> vnext;
+                R2<RT> acc_p = clamp_dyn<RT>(vn, C.v_max, acc_tmp, C.dt, C.inv_dt, vnext);
+                bool diff = (acc_tmp.x != acc_p.x) | (acc_tmp.y != acc_p.y);
+                R2<RT> u;
                 u.x = diff ? (acc_p.x - acc.x) / C.dt : j1.x;
                 u.y = diff ? (acc_p.y - acc.y) / C.dt : j1.y;
-            } else {
-                u.x = diff ? (acc_p.x - acc.x) * C.inv_dt : j1.x;
-                u.y = diff ? (acc_p.y - acc.y) * C.inv_dt : j1.y;
+                // mj_step with dyntype=integrator, actearly (PL:307-310): act += dt*ctrl, qacc = act_new
+                qacc.x = acc.x + C.dt * u.x;
+                qacc.y = acc.y + C.dt * u.y;
+            } else {  // PL:442-443; mj_step with a plain force actuator of gain = mass: qacc = ctrl
+                R2<RT> vnext;
+                qacc = clamp_dyn<RT>(vn, C.v_max, a, C.dt, C.inv_dt, vnext);
             }
-            // mj_step with dyntype=integrator, actearly (PL:307-310): act += dt*ctrl, qacc = act_new
-            inc_a.x = C.dt * u.x;
-            inc_a.y = C.dt * u.y;
-            if constexpr (Math<RT>::literal) {
-                qacc.x = acc.x + inc_a.x; qacc.y = acc.y + inc_a.y;
-            } else {
-                qacc.x = a0.x + (da.x + inc_a.x); qacc.y = a0.y + (da.y + inc_a.y);
-            }
-        } else {  // PL:442-443; mj_step with a plain force actuator of gain = mass: qacc = ctrl
-            R2<RT> vnext;
-            qacc = clamp_dyn<RT>(vn, C.v_max, a, C.dt, C.inv_dt, vnext);
-        }
-        // MuJoCo's default (semi-implicit) Euler step on a free, undamped, gravity-compensated body (BE:878-883, BE:1132):
-        // v += dt*qacc, then p += dt*v_new
-        if (!lane_of(frozen_m)) {
-            if constexpr (Math<RT>::literal) {
+            // MuJoCo's default (semi-implicit) Euler step on a free, undamped, gravity-compensated body (BE:878-883, BE:1132)
+            if (!lane_of(frozen_m)) {
                 acc = qacc;
                 v.x = v.x + C.dt * qacc.x; v.y = v.y + C.dt * qacc.y;
                 p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
-            } else {
-                if constexpr (JERK) { da.x += inc_a.x; da.y += inc_a.y; }
-                acc = qacc;
-                dv.x += C.dt * qacc.x; dv.y += C.dt * qacc.y;
+            }
+        } else {
+            // throughput mode, acceleration actions only. With t = v_read + dt*a (v_read = v + noise):
+            //   not clamped (|t| < v_max):  ctrl = a                      -> v' = v + dt*a                (PL:636-637)
+            //   clamped:                    ctrl = (v_max t/|t| - v_read)/dt -> v' = v_max t/|t| - noise  (PL:640-643)
+            // written on the displacement dv = v - v0 so that the small increments are summed among themselves.
+            R2<RT> t{v.x + dta.x, v.y + dta.y}, nv{(RT)0, (RT)0};
+            RT n2 = t.x * t.x + t.y * t.y;
+            if constexpr (NOISE) {
+                // the velocity reading only matters if the speed clamp can fire (PL:634): |v + dt*a| within band_v of v_max
+                if (eager | (__ballot(!(n2 < vlim2)) != 0ull)) {
+                    const R2<RT> n = rng_normal_pair<RT>(key, 3u * (uint32_t)cyc);  // PL:430
+                    nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
+                    t.x += nv.x; t.y += nv.y;
+                    n2 = t.x * t.x + t.y * t.y;
+                }
+            }
+            const bool cl = n2 >= C.v_max * C.v_max;  // PL:634, inclusive
+            const RT sc = C.v_max * Math<RT>::rsqrt_(n2);
+            if (!lane_of(frozen_m)) {
+                dv.x = cl ? (t.x * sc - nv.x) - v0.x : dv.x + dta.x;
+                dv.y = cl ? (t.y * sc - nv.y) - v0.y : dv.y + dta.y;
                 v.x = v0.x + dv.x; v.y = v0.y + dv.y;
-                dp.x += C.dt * v.x; dp.y += C.dt * v.y;
+                dp.x += C.dt * v.x; dp.y += C.dt * v.y;  // semi-implicit Euler: the position moves with the NEW velocity
                 p.x = p0.x + dp.x; p.y = p0.y + dp.y;
             }
         }
         // BE:1888-1901: wall check and mover check, each on its own noisy position read
-        const R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
-        const bool w = live & !pos_valid_circle<RT>(T, P, pw.x, pw.y, cw_step);
-        const R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, key, 3u * (uint32_t)cyc + 2u);
-        const bool hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step);
+        bool w, hit;
+        if constexpr (NOISE) {
+            bool unc;
+            w = live & !pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &unc);
+            if (eager | (__ballot(live & unc) != 0ull)) {
+                const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
+                w = live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
+            }
+            const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
+            hit = live & (md <= pair_thr);  // BE:409, inclusive
+            if (eager | (__ballot(live & (absr(md - pair_thr) <= pair_band)) != 0ull)) {
+                const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, 3u * (uint32_t)cyc + 2u);
+                hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step);
+            }
+        } else {
+            w = live & !pos_valid_circle<RT, FULL>(T, P, p.x, p.y, cw_step);
+            hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(p.x, p.y), C.max_csum_step);
+        }
         // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle.
         // wc_m / mc_m collect the raw per-lane hits of not-yet-frozen envs; only the freeze decision needs the per-env OR now.
         const unsigned long long wb = __ballot(w) & ~frozen_m, mb = __ballot(hit) & ~frozen_m;
@@ -260,7 +301,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         }
         R2<RT> rp = p, rg = g;
         bool rwc, rmc;
-        Obs<RT> ro = group_reset<ST, RT, LPE, NOISE>(P, T, env_global, mv, mvc, live, need, c, rp, rg, rwc, rmc);
+        Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL>(P, T, env_global, mv, mvc, live, need, c, rp, rg, rwc, rmc);
         if (need) {
             p = rp; g = rg;
             v = R2<RT>{(RT)0, (RT)0};
@@ -288,7 +329,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 // -----------------------------------------------------------------------------------------------------------------
 // reset (explicit): BE:1770-1833 for the envs selected by mask (all when mask == NULL)
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE>
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL>
 __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int M = P.M;
@@ -305,10 +346,10 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];
     R2<RT> p = load2<ST, RT>(P.pos, idx), g = load2<ST, RT>(P.goal, idx);
     if (mv >= M) p.x = p.y = far_away<RT>();
-    if (Math<RT>::literal || !P.layout_full) stage_tables(lds, P.tables, P.table_bytes);
+    if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
-    Obs<RT> o = group_reset<ST, RT, LPE, NOISE>(P, T, env_global, mv, mvc, live, need, c, p, g, wc, mc);
+    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL>(P, T, env_global, mv, mvc, live, need, c, p, g, wc, mc);
     if (live & need) {
         const R2<RT> zero{(RT)0, (RT)0};
         store2<ST, RT>(P.pos, idx, p);
@@ -323,15 +364,23 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
 // -----------------------------------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipError_t launch_one(bool is_reset, const KParams &P, hipStream_t s) {
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL> static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) {
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    const unsigned lds = FULL ? 0u : P.table_bytes;
     if (is_reset) {
-        hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE>), dim3(grid), dim3(BLOCK), P.table_bytes, s, P);
+        hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL>), dim3(grid), dim3(BLOCK), lds, s, P);
     } else {
-        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE>), dim3(grid), dim3(BLOCK), P.table_bytes, s, P);
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL>), dim3(grid), dim3(BLOCK), lds, s, P);
     }
     return hipGetLastError();
+}
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipError_t launch_one(bool is_reset, const KParams &P, hipStream_t s) {
+    // the throughput-mode wall check has a table-free form for grids without holes (pos_valid_circle): separate kernels
+    if constexpr (!Math<RT>::literal) {
+        if (P.layout_full) return launch_kernel<ST, RT, LPE, JERK, NOISE, true>(is_reset, P, s);
+    }
+    return launch_kernel<ST, RT, LPE, JERK, NOISE, false>(is_reset, P, s);
 }
 template <typename ST, typename RT, int LPE> static hipError_t launch_flags(bool is_reset, const KParams &P, hipStream_t s) {
     const bool jerk = P.learn_jerk != 0, noise = P.noise != 0;

@@ -287,6 +287,35 @@ def test_sharding_invariance_and_determinism(gpr):
         assert torch.equal(ow[3], torch.cat([ol[3], oh[3]]))
 
 
+def test_lazy_noise_is_exact(gpr, monkeypatch):
+    """The kernels skip a noise draw when no possible value of it could change the outcome of the comparison it feeds.
+    GPR_EAGER_NOISE=1 (read at env creation) draws everything: both must produce bit-identical rollouts."""
+    for layout, M, prec in ((np.ones((6, 6)), 4, 'f32'), (HOLES, 3, 'f32'), (np.ones((5, 5)), 2, 'f64'), (np.ones((4, 6)), 2, 'f32')):
+        E = 2048 if prec == 'f32' else 256
+        kw = dict(num_envs=E, precision=prec, std_noise=np.array([2e-5, 1e-5, 0.0]), learn_jerk=(prec == 'f64'))
+        monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
+        lazy = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
+        monkeypatch.setenv('GPR_EAGER_NOISE', '1')
+        eager = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
+        monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
+        lazy.reset(seed=11); eager.reset(seed=11)
+        g = torch.Generator(device='cuda').manual_seed(5)
+        lim = lazy.j_max if lazy.learn_jerk else lazy.a_max
+        n_done = 0
+        for step in range(80):
+            a = ((torch.rand(E, 2 * M, device='cuda', generator=g) * 2 - 1) * lim).to(lazy.dtype)
+            if step % 3 == 0:
+                a = a.sign() * lim  # saturate: drives movers into the speed clamp, where the velocity noise matters
+            ol = lazy.step(a); oe = eager.step(a)
+            for k in ('observation', 'achieved_goal', 'desired_goal'):
+                assert torch.equal(ol[0][k], oe[0][k]), (step, k)
+            assert torch.equal(ol[1], oe[1]) and torch.equal(ol[2], oe[2]) and torch.equal(ol[3], oe[3])
+            assert torch.equal(lazy.pos, eager.pos) and torch.equal(lazy.vel, eager.vel)
+            n_done += int(ol[2].sum())
+        assert n_done > 0
+        lazy.close(); eager.close()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # full benchmark size: size-independent properties
 # ----------------------------------------------------------------------------------------------------------------------
