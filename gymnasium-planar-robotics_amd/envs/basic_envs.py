@@ -44,6 +44,7 @@ class VecBasicPlanarRoboticsEnv:
         render_mode: str | None = None,
         collision_params: dict[str, Any] | None = None,
         device: str | torch.device = 'cuda',
+        _host_only: bool = False,
     ) -> None:
         if render_mode is not None:
             raise ValueError('rendering is out of scope of the GPU engine: use render_mode=None')
@@ -107,14 +108,18 @@ class VecBasicPlanarRoboticsEnv:
 
         self.num_envs = int(num_envs)
         assert self.num_envs >= 1
+        self.cycle_time = 0.001  # MuJoCo option/timestep of the reference's MJCF (BE:1132, BE:283)
+        self._handle = None
+        self._host_only = bool(_host_only)  # configuration / table logic only (CPU unit tests); nothing can be computed
+        if self._host_only:
+            self.device, self._lib = None, None
+            return
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('the planar-robotics engine runs on MI355X only (device must be a CUDA/ROCm device); there is no CPU path')
         if self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self._lib = _native.load()
-        self._handle = None
-        self.cycle_time = 0.001  # MuJoCo option/timestep of the reference's MJCF (BE:1132, BE:283)
 
     # ------------------------------------------------------------------------------------------------------------
     # ctor-time tables

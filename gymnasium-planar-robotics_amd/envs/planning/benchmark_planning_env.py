@@ -80,6 +80,7 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         env_id_offset: int = 0,
         max_reset_trials: int = 10000,
         alias_desired_goal: bool = False,
+        _host_only: bool = False,
     ) -> None:
         if show_2D_plot and mover_colors_2D_plot is None:
             raise ValueError('Please specify the colors of the movers for the 2D plot.')  # PL:223-224
@@ -89,7 +90,7 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         assert autoreset_mode in _native.AUTORESET, f'autoreset_mode must be one of {list(_native.AUTORESET)}'
         super().__init__(layout_tiles=layout_tiles, num_movers=num_movers, num_envs=num_envs, tile_params=tile_params,
                          mover_params=mover_params, initial_mover_zpos=initial_mover_zpos, std_noise=std_noise, render_mode=render_mode,
-                         collision_params=collision_params, device=device)
+                         collision_params=collision_params, device=device, _host_only=_host_only)
         self.learn_jerk = bool(learn_jerk)
         self.num_cycles = int(num_cycles)
         self.v_max, self.a_max, self.j_max = float(v_max), float(a_max), float(j_max)
@@ -129,6 +130,8 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         else:
             self.min_goal_dist = 2 * np.linalg.norm(self.c_size + self.c_size_offset, ord=2)
 
+        if self._host_only:
+            return
         self._create_handle(env_id_offset=self.env_id_offset, num_cycles=self.num_cycles, v_max=self.v_max, a_max=self.a_max,
                             j_max=self.j_max, learn_jerk=self.learn_jerk, threshold_pos=self.threshold_pos,
                             max_episode_steps=max_episode_steps, autoreset_mode=autoreset_mode, min_xy_pos=self.min_xy_pos,

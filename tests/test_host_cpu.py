@@ -1,0 +1,237 @@
+"""CPU tests (no GPU): host-side logic, the C-ABI surface, the multi-process path over gloo, the engine's RNG spec."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_json
+
+import gymnasium_planar_robotics_amd as gpr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# C ABI: the library loads and exports every symbol include/gpr.h declares (no compute call without a GPU)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'gpr.h')).read()
+    declared = set(re.findall(r'\b(gpr_[a-zA-Z0-9_]+)\s*\(', header))
+    assert len(declared) >= 15
+    lib = gpr._native.load()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} is declared in include/gpr.h but not exported by libgpr_hip.so'
+    assert declared == set(gpr._native.EXPORTS), 'the ctypes binding and the header disagree on the entry points'
+    assert b'gfx950' in lib.gpr_version()
+
+
+def test_c_abi_struct_layout_matches_header():
+    """field order / count of the ctypes mirrors follows the header's struct declarations"""
+    header = open(os.path.join(ROOT, 'include', 'gpr.h')).read()
+
+    def fields(struct_name):
+        end = header.index('} %s;' % struct_name)
+        body = header[header.rindex('typedef struct {', 0, end) + len('typedef struct {'):end]
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        names = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(','):
+                names.append(re.search(r'\*?\s*([a-zA-Z_][a-zA-Z0-9_]*)\s*(\[\d+\])?\s*$', part.strip()).group(1))
+        return names
+
+    assert fields('gpr_config') == [f[0] for f in gpr._native.GprConfig._fields_]
+    assert fields('gpr_state') == [f[0] for f in gpr._native.GprState._fields_]
+    assert fields('gpr_step_out') == [f[0] for f in gpr._native.GprStepOut._fields_]
+
+
+def test_invalid_configuration_is_reported_not_crashed():
+    lib = gpr._native.load()
+    cfg = gpr._native.GprConfig()  # all zero: num_envs = 0
+    handle = ctypes.c_void_p()
+    rc = lib.gpr_create(ctypes.byref(cfg), ctypes.byref(handle))
+    assert rc == gpr._native.E_INVALID and not handle.value
+    assert b'num_envs' in lib.gpr_last_error(None)
+    with pytest.raises(gpr._native.GprError):
+        gpr._native.check(rc)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError):
+        gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 1, num_envs=4)  # default device 'cuda': must fail loudly, not fall back
+    with pytest.raises(RuntimeError):
+        gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 1, num_envs=4, device='cpu')
+    with pytest.raises(RuntimeError):
+        gpr.geometry_2D_utils.check_line_segments_intersect(np.zeros((1, 2)), np.ones((1, 2)), np.zeros((1, 2)), np.ones((1, 2)), device='cpu')
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# host mirror of the reference's constructor logic, against the golden constants
+# ----------------------------------------------------------------------------------------------------------------------
+def test_ctor_tables_match_reference_constants():
+    for c in load_json('constants.json'):
+        env = gpr.VecBenchmarkPlanningEnv(c['layout'], 1, collision_params=c['collision_params'], _host_only=True)
+        assert np.array_equal(env.x_pos_tiles, c['x_pos_tiles']) and np.array_equal(env.y_pos_tiles, c['y_pos_tiles'])
+        masks = {'idx_3x3': np.ones((3, 3)), 'idx_2x2_bl': np.array([[1, 1], [0, 1]]), 'idx_2x2_br': np.array([[1, 1], [1, 0]]),
+                 'idx_2x2_tl': np.array([[0, 1], [1, 1]]), 'idx_2x2_tr': np.array([[1, 0], [1, 1]])}
+        for key, mask in masks.items():
+            ix, iy = env.get_tile_indices_mask(mask)
+            assert np.array_equal(ix, c[key][0]) and np.array_equal(iy, c[key][1]), key
+        assert np.array_equal(env.min_xy_pos, c['min_xy_pos']) and np.array_equal(env.max_xy_pos, c['max_xy_pos'])
+        assert float(env.min_goal_dist) == c['min_goal_dist']
+        assert np.array_equal(env.single_observation_space['desired_goal'].high, c['goal_space_high'])
+        assert np.array_equal(env.single_action_space.low, c['action_low']) and np.array_equal(env.single_action_space.high, c['action_high'])
+        assert env.cycle_time == c['cycle_time'] and env.num_cycles == c['num_cycles']
+        assert (env.v_max, env.a_max, env.j_max, env.threshold_pos, env.reward_success) == (c['v_max'], c['a_max'], c['j_max'], c['threshold_pos'], c['reward_success'])
+        assert np.array_equal(env.std_noise, c['std_noise']) and env.mover_names == c['mover_names']
+
+
+def test_interface_mirrors_the_reference():
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((4, 5)), 3, num_envs=7, learn_jerk=True, _host_only=True)
+    sp = env.single_observation_space
+    assert list(sp.keys()) == ['observation', 'achieved_goal', 'desired_goal']
+    assert sp['observation'].shape == (12,) and sp['achieved_goal'].shape == (6,)  # velocities then accelerations (PL:560)
+    assert env.observation_space['observation'].shape == (7, 12) and env.action_space.shape == (7, 6)
+    assert env.single_action_space.high[0] == env.j_max  # jerk actions (PL:257-259)
+    assert env.get_c_size_arr(0.11, 4).shape == (4, 1)
+    with pytest.raises(ValueError):  # PL:223-224
+        gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 1, show_2D_plot=True, _host_only=True)
+    with pytest.raises(ValueError):
+        gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 1, render_mode='human', _host_only=True)
+    with pytest.raises(AssertionError):  # BE:1471-1476
+        gpr.VecBenchmarkPlanningEnv(np.array([[1, 2], [0, 1]]), 1, _host_only=True)
+    with pytest.raises(AssertionError):  # BE:1553-1558
+        gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 2, collision_params={'shape': 'box', 'size': 0.1}, _host_only=True)
+    with pytest.raises(AssertionError):
+        gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 2, collision_params={'offset': -0.1}, _host_only=True)
+    box = gpr.spaces.Box(-1.0, 1.0, shape=(3,))
+    assert box.contains(np.zeros(3)) and not box.contains(np.full(3, 2.0)) and box.sample(np.random.default_rng(0)).shape == (3,)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sharding + rollout buffer
+# ----------------------------------------------------------------------------------------------------------------------
+def test_shard_range_partitions_every_env_once():
+    for n, w in ((65536, 8), (10, 3), (7, 7), (100, 1)):
+        ranges = [gpr.distributed.shard_range(n, r, w) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_rollout_buffer_layout():
+    import torch
+    buf = gpr.distributed.RolloutBuffer(5, 8, 4, 8, dtype=torch.float32, device='cpu')
+    assert buf['observation'].shape == (5, 8, 8) and buf['reward'].shape == (5, 8) and buf['terminated'].dtype == torch.uint8
+    names = [f.name for f in buf.fields]
+    assert names == ['observation', 'achieved_goal', 'desired_goal', 'action', 'reward', 'terminated', 'truncated']
+    # fields do not overlap and views alias the one storage
+    spans = sorted((f.offset, f.offset + f.nbytes) for f in buf.fields)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= buf.nbytes
+    buf['reward'][2, 3] = 7.5
+    assert buf.slot(2)['reward'][3] == 7.5 and buf.slot(2)['reward'].is_contiguous()
+    out = buf.flush()
+    assert out['reward'].shape == (1, 5, 8) and out['reward'][0, 2, 3] == 7.5
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import gymnasium_planar_robotics_amd as gpr
+rank, local_rank, world = gpr.distributed.init_from_env('gloo')
+assert world == 2 and dist.get_backend() == 'gloo'
+start, stop = gpr.distributed.shard_range(12, rank, world)
+buf = gpr.distributed.RolloutBuffer(3, stop - start, 2, 4, dtype=torch.float32, device='cpu')
+for t in range(3):
+    s = buf.slot(t)
+    env_ids = torch.arange(start, stop, dtype=torch.float32)
+    s['reward'].copy_(env_ids * 10 + t)
+    s['observation'].copy_(env_ids[:, None] + torch.arange(4)[None, :] * 0.25)
+    s['terminated'].copy_((torch.arange(start, stop) % 2).to(torch.uint8))
+g = buf.flush()   # the ONE collective of a rollout
+assert g['reward'].shape == (2, 3, 6)
+whole = g['reward'].permute(1, 0, 2).reshape(3, 12)
+assert torch.equal(whole, (torch.arange(12, dtype=torch.float32) * 10)[None, :] + torch.arange(3, dtype=torch.float32)[:, None])
+assert torch.equal(g['terminated'].permute(1, 0, 2).reshape(3, 12)[0], (torch.arange(12) % 2).to(torch.uint8))
+assert torch.equal(g['observation'][1, 0, :, 1], torch.arange(6, 12, dtype=torch.float32) + 0.25)
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_two_process_gather_over_gloo(tmp_path):
+    """N > 1 path on CPU: two ranks, gloo, one all-gather of the packed rollout buffer"""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    port = 29000 + os.getpid() % 2000
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f'rank {r} ok' in o, o[-2000:]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the engine's RNG spec (as restated by the oracle) and the oracle env's own invariants
+# ----------------------------------------------------------------------------------------------------------------------
+def test_rng_spec_statistics(oracle):
+    key = oracle.rng_key(7, 3, 1, 12345, 2)
+    assert key != oracle.rng_key(7, 3, 1, 12345, 3) != oracle.rng_key(7, 4, 1, 12345, 2)
+    u = oracle.rng_draws(key, 40000).astype(np.float64) / 2 ** 32
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() * 12 - 1) < 0.03
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.02
+    hist = np.histogram(u, bins=64, range=(0, 1))[0]
+    assert ((hist - 625) ** 2 / 625).sum() < 120  # chi-square, 63 dof (p ~ 1e-5 cut)
+    n = oracle.rng_normals(key, 20000)
+    flat = n.ravel()
+    assert abs(flat.mean()) < 0.02 and abs(flat.std() - 1) < 0.02 and abs(np.corrcoef(n[:, 0], n[:, 1])[0, 1]) < 0.03
+    assert np.hypot(n[:, 0], n[:, 1]).max() <= 4.70965  # sqrt(32 ln 2): what the kernels' lazy-noise bands rely on
+    from scipy import stats
+    assert stats.kstest(flat, 'norm').pvalue > 1e-4
+    # streams of neighbouring movers / envs / ticks are uncorrelated
+    other = oracle.rng_normals(oracle.rng_key(7, 3, 1, 12346, 2), 20000).ravel()
+    assert abs(np.corrcoef(flat, other)[0, 1]) < 0.03
+
+
+def test_oracle_env_sharding_and_determinism(oracle):
+    kw = dict(std_noise=1e-5)
+    whole = oracle.OraclePlanningEnv(np.ones((6, 6)), 4, 64, **kw)
+    lo = oracle.OraclePlanningEnv(np.ones((6, 6)), 4, 32, env_id_offset=0, **kw)
+    hi = oracle.OraclePlanningEnv(np.ones((6, 6)), 4, 32, env_id_offset=32, **kw)
+    for e in (whole, lo, hi):
+        e.reset(seed=5)
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        a = rng.uniform(-10, 10, size=(64, 8))
+        w, l, h = whole.step(a), lo.step(a[:32]), hi.step(a[32:])
+        for k in ('observation', 'achieved_goal', 'reward', 'terminated', 'truncated'):
+            assert np.array_equal(w[k], np.concatenate([l[k], h[k]]))
+    again = oracle.OraclePlanningEnv(np.ones((6, 6)), 4, 64, **kw)
+    assert np.array_equal(again.reset(seed=5)['achieved_goal'], oracle.OraclePlanningEnv(np.ones((6, 6)), 4, 64, **kw).reset(seed=5)['achieved_goal'])
+
+
+def test_oracle_env_matches_reference_semantics(oracle):
+    """reward / terminated / info algebra (PL:478, 519-531, 597), TimeLimit, freeze-at-collision (BE:1904)"""
+    env = oracle.OraclePlanningEnv(np.ones((6, 6)), 4, 256, std_noise=0.0, autoreset='disabled')
+    env.reset(seed=1)
+    rng = np.random.default_rng(1)
+    seen_term = False
+    for step in range(50):
+        before = env.pos.copy()
+        r = env.step(rng.uniform(-10, 10, size=(256, 8)))
+        coll = r['mover_collision'] | r['wall_collision']
+        assert np.array_equal(r['reward'] == -50, coll) and np.array_equal(r['terminated'], coll | r['is_success'])
+        assert np.array_equal(r['truncated'], env.elapsed >= 50)
+        moved = np.abs(env.pos - before).max(axis=1)
+        assert (moved <= 0.04 * 2.0 + 1e-9).all()  # 40 cycles x 1 ms x v_max
+        seen_term |= bool(r['terminated'].any())
+    assert seen_term and r['truncated'].all()
