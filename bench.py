@@ -38,6 +38,20 @@ def algorithmic_bytes_per_env_step(num_movers: int) -> int:
     return 72 * num_movers + 17
 
 
+def measured_traffic(num_envs: int, num_movers: int):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/round1_hbm_traffic.json: FETCH_SIZE
+    and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read
+    from inside this process; None when the profiled configuration is not the one being run."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'round1_hbm_traffic.json')) as f:
+            d = json.load(f)
+        if d['envs'] == num_envs and d['movers'] == num_movers:
+            return d['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def run_gpu(args, rank, local_rank, world, std_noise):
     import torch.distributed as dist
 
@@ -156,7 +170,7 @@ def main():
                 'sigma0_env_steps_per_s': world * E * K / wall0, 'sigma0_kernel_us': gpu_ms0 * 1e3 / K,
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'gpr::k_step<float,float,4,false,true>', 'kernel_us': kernel_s * 1e6,
+                         'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true>', 'kernel_us': kernel_s * 1e6,
                          'algorithmic_bytes_per_env_step': B},
         }
         if world == 1 and not args.no_cpu_baseline:
