@@ -316,7 +316,6 @@ int gpr_seed(gpr_env *env, uint64_t seed) {
 int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_reset: NULL handle");
     if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_reset: call gpr_bind_state first");
-    if (env->cfg.c_shape != GPR_SHAPE_CIRCLE) return fail(env, GPR_E_UNSUPPORTED, "gpr_reset: the fused env kernels support the 'circle' collision shape");
     int rc = check_out(env, out);
     if (rc != GPR_OK) return rc;
     KParams P = make_params(env, out, false);
@@ -330,7 +329,6 @@ int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_step: NULL handle");
     if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_step: call gpr_bind_state first");
     if (!action_dev) return fail(env, GPR_E_INVALID, "gpr_step: action is NULL");
-    if (env->cfg.c_shape != GPR_SHAPE_CIRCLE) return fail(env, GPR_E_UNSUPPORTED, "gpr_step: the fused env kernels support the 'circle' collision shape");
     int rc = check_out(env, out);
     if (rc != GPR_OK) return rc;
     KParams P = make_params(env, out, false);

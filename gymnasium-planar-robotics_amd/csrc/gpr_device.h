@@ -409,7 +409,8 @@ template <typename RT> __device__ __forceinline__ bool rects_intersect_v(const R
 // one tile, box shape (BE:560-572, 580-655, 657-783). v*: the mover's vertices; cx/cy: tile centre tables.
 template <typename RT>
 __device__ __forceinline__ bool tile_valid_box(const Tables<RT> &T, const RT *tcx, const RT *tcy, int Tx, int Ty, int ix, int iy, RT xlo,
-                                               RT xhi, RT ylo, RT yhi, const RT *vx, const RT *vy, RT thx, RT thy) {
+                                               RT xhi, RT ylo, RT yhi, const RT *vx, const RT *vy, RT thx, RT thy,
+                                               bool *corner_tested = nullptr) {
     const uint32_t lut = T.lut[ix * Ty + iy];
     uint32_t sum = 0;
 #pragma unroll
@@ -429,6 +430,7 @@ __device__ __forceinline__ bool tile_valid_box(const Tables<RT> &T, const RT *tc
         if (bit(0, 0) & bit(dx, 0) & bit(0, dy) & (bit(dx, dy) ^ 1u)) {
             int mx = ix + dx, my = iy + dy;
             if (mx < 0 || my < 0 || mx >= Tx || my >= Ty) continue;  // reference: mask_idx_* (BE:659,691,723,755)
+            if (corner_tested) *corner_tested = true;
             RT bx[4], by[4];
             rect_vertices<RT>(tcx[mx], tcy[my], (RT)1, (RT)0, (RT)0, (RT)0, thx, thy, bx, by);
             if (rects_intersect_v<RT>(vx, vy, bx, by)) valid = false;
@@ -464,6 +466,79 @@ __device__ __forceinline__ bool pos_valid_any(const Tables<RT> &T, const RT *tcx
         }
     }
     return valid3 | (any & all);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 'box' collision shape inside the fused env kernels
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename RT> struct Pose {
+    RT x, y, qw, qx, qy, qz;  // qpos without z
+};
+
+// qpos_is_valid (BE:459-788) for one rotated rectangle. UNC: also report whether moving the centre by up to `band` per axis
+// and every vertex by up to `band` could change the verdict (conservative).
+template <typename RT, bool UNC>
+__device__ __forceinline__ bool pos_valid_box(const Tables<RT> &T, const KParams &P, const Pose<RT> &q, RT c0, RT c1, RT band, bool *uncertain) {
+    const int Tx = P.Tx, Ty = P.Ty;
+    const Cst<RT> &C = cst<RT>(P);
+    RT vx[4], vy[4];
+    rect_vertices<RT>(q.x, q.y, q.qw, q.qx, q.qy, q.qz, c0, c1, vx, vy);  // BE:496-497
+    const int gx = clampi(Math<RT>::floor_int(q.x * C.inv_wx), 0, Tx - 1), gy = clampi(Math<RT>::floor_int(q.y * C.inv_wy), 0, Ty - 1);
+    bool any = false, all = true, valid3 = false, corner = false;
+    for (int a = gx - 1; a <= gx + 1; ++a) {
+        if (a < 0 || a >= Tx) continue;
+        const RT *fa = T.ax + 4 * a;
+        const bool in_x = (fa[0] <= q.x) & (q.x <= fa[1]);
+        for (int b = gy - 1; b <= gy + 1; ++b) {
+            if (b < 0 || b >= Ty) continue;
+            const RT *fb = T.ay + 4 * b;
+            if (!(in_x & (fb[0] <= q.y) & (q.y <= fb[1]))) continue;  // BE:508-513
+            any = true;
+            valid3 |= (T.nbr[a * Ty + b] == 0x1FFu);  // BE:530-538
+            all &= tile_valid_box<RT>(T, T.cx, T.cy, Tx, Ty, a, b, fa[0], fa[1], fb[0], fb[1], vx, vy, C.tile_hx, C.tile_hy, &corner);
+        }
+    }
+    if constexpr (UNC) {
+        // every decision above compares the centre or a vertex with an edge line of the centre's tile (or runs a corner test)
+        const RT *fa = T.ax + 4 * gx, *fb = T.ay + 4 * gy;
+        bool unc = corner | !((q.x - fa[0] > band) & (fa[1] - q.x > band) & (q.y - fb[0] > band) & (fb[1] - q.y > band));
+        for (int r = 0; r < 4; ++r)
+            unc |= (absr(vx[r] - fa[0]) <= band) | (absr(vx[r] - fa[1]) <= band) | (absr(vy[r] - fb[0]) <= band) | (absr(vy[r] - fb[1]) <= band);
+        *uncertain = unc;
+    }
+    return valid3 | (any & all);
+}
+
+// check_mover_collision, box branch (BE:410-422), seen from one lane: partners at rotation distance 1..LPE/2.
+//   near: some partner passes the distance pre-filter dist <= 4*max_size (+ extra, for the lazy-noise decision)
+//   hit : the pre-filter (without extra) passes and the two rectangles intersect
+template <typename RT, int LPE, int D> struct BoxSweep {
+    static __device__ __forceinline__ void run(const RT *vx, const RT *vy, RT x, RT y, RT cmax, RT extra, bool with_rects, bool &hit, bool &near) {
+        if constexpr (D <= LPE / 2 && D >= 1 && LPE > 1) {
+            const RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
+            const RT dist = Math<RT>::sqrt_(dx * dx + dy * dy);                 // BE:411
+            const RT ms = fmax(cmax, rot<LPE, D>(cmax));                        // BE:412
+            const RT lim = (RT)2 * (absr(ms) + absr(ms));                       // BE:413-414 (ord = 1 norm of (ms, ms))
+            near |= dist <= lim + extra;
+            const bool pre = dist <= lim;
+            if (with_rects && (__ballot(pre) != 0ull)) {                        // rectangles only when some lane needs them
+                RT ox[4], oy[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ox[r] = rot<LPE, D>(vx[r]); oy[r] = rot<LPE, D>(vy[r]); }
+                hit |= pre & rects_intersect_v<RT>(vx, vy, ox, oy);            // BE:417-422
+            }
+            BoxSweep<RT, LPE, D + 1>::run(vx, vy, x, y, cmax, extra, with_rects, hit, near);
+        }
+    }
+};
+template <typename RT, int LPE>
+__device__ __forceinline__ bool box_pair_hit(const Pose<RT> &q, RT c0, RT c1, RT extra, bool with_rects, bool *near_out) {
+    RT vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0};
+    if (with_rects) rect_vertices<RT>(q.x, q.y, q.qw, q.qx, q.qy, q.qz, c0, c1, vx, vy);
+    bool hit = false, near = false;
+    BoxSweep<RT, LPE, 1>::run(vx, vy, q.x, q.y, fmax(c0, c1), extra, with_rects, hit, near);
+    if (near_out) *near_out = near;
+    return hit;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,19 @@ template <typename RT, bool NOISE> __device__ __forceinline__ R2<RT> noisy(R2<RT
     }
 }
 
+// a noisy qpos read for the box shape (BE:828 perturbs all seven components): x,y take normal pair q, the identity quaternion
+// takes pairs q+1 (w,x) and q+2 (y,z); z is never looked at
+template <typename RT, bool NOISE> __device__ __forceinline__ Pose<RT> noisy_pose(R2<RT> p, RT sigma, uint32_t key, uint32_t q) {
+    Pose<RT> o{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0};
+    if constexpr (NOISE) {
+        const R2<RT> n0 = rng_normal_pair<RT>(key, q), n1 = rng_normal_pair<RT>(key, q + 1u), n2 = rng_normal_pair<RT>(key, q + 2u);
+        o.x = p.x + sigma * n0.x; o.y = p.y + sigma * n0.y;
+        o.qw = (RT)1 + sigma * n1.x; o.qx = (RT)0 + sigma * n1.y;
+        o.qy = (RT)0 + sigma * n2.x; o.qz = (RT)0 + sigma * n2.y;
+    }
+    return o;
+}
+
 template <typename RT> struct Obs {
     R2<RT> vel, ag;  // noisy velocity (observation) and noisy position (achieved_goal)
     RT reward;
@@ -52,12 +65,15 @@ __device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint3
 
 // _reset_callback (PL:355-418) + the collision flags / observation of reset() (BE:1797-1831) for the env groups whose
 // `need` is set. Wave-cooperative: every lane of the wavefront must call it (it votes).
-template <typename ST, typename RT, int LPE, bool NOISE, bool FULL>
+template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE>
 __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, bool live,
-                                               bool need, RT c, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
+                                               bool need, RT c, RT c1, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
     const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);  // BE:487 with add_safety_offset=True
+    const RT ws0 = (c + C.c_offset_wall) + C.c_offset, ws1 = (c1 + C.c_offset_wall) + C.c_offset;  // box: wall sizes, BE:487
+    const RT ps0 = c + C.c_offset, ps1 = c1 + C.c_offset;                                        // box: pair sizes with offset, BE:390
+    constexpr uint32_t R = SHAPE == 0 ? 1u : 3u;  // normal pairs per noisy qpos read
     const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, (uint32_t)mvc);
     const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
     const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, (uint32_t)mvc);
@@ -71,8 +87,15 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(ks, 2u * (uint32_t)trial));  // PL:377
         cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(ks, 2u * (uint32_t)trial + 1u));
         if (mv >= M) cn.x = cn.y = far_away<RT>();
-        bool w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                          // PL:379
-        bool hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.max_csum_safe);  // PL:381-383
+        bool w, hit;
+        if constexpr (SHAPE == 0) {
+            w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                   // PL:379
+            hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.max_csum_safe);       // PL:381-383
+        } else {
+            const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
+            w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
+            hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
+        }
         bool bad = group_any<LPE>(w | hit);
         if (pending) { cand = cn; pending = bad; }
     }
@@ -86,7 +109,12 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(kg, 2u * (uint32_t)trial));  // PL:402
         cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(kg, 2u * (uint32_t)trial + 1u));
         if (mv >= M) cn.x = cn.y = far_away<RT>();
-        bool w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                              // PL:403-404
+        bool w;  // PL:403-404
+        if constexpr (SHAPE == 0) {
+            w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);
+        } else {
+            w = live & !pos_valid_box<RT, false>(T, P, Pose<RT>{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0}, ws0, ws1, (RT)0, nullptr);
+        }
         bool close = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);  // PL:407-413, strict
         bool bad = group_any<LPE>(w | close);
         if (pending) { cand = cn; pending = bad; }
@@ -94,11 +122,18 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     if (need) g = cand;
 
     // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
-    R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
-    wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
-    R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, 1u);
-    mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
-    return observe<ST, RT, LPE, NOISE>(P, kn, 2u, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
+    if constexpr (SHAPE == 0) {
+        R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
+        wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
+        R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, R);
+        mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+    } else {
+        const Pose<RT> qw_ = noisy_pose<RT, NOISE>(p, C.sig_p, kn, 0u);
+        wc = group_any<LPE>(live & !pos_valid_box<RT, false>(T, P, qw_, ws0, ws1, (RT)0, nullptr));
+        const Pose<RT> qp = noisy_pose<RT, NOISE>(p, C.sig_p, kn, R);
+        mc = group_any<LPE>(live & box_pair_hit<RT, LPE>(qp, c + C.c_offset * (RT)0, c1 + C.c_offset * (RT)0, (RT)0, true, nullptr));
+    }
+    return observe<ST, RT, LPE, NOISE>(P, kn, 2u * R, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
 }
 
 template <typename ST, typename RT>
@@ -130,7 +165,7 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 // -----------------------------------------------------------------------------------------------------------------
 // step
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL>
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
 __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
@@ -155,6 +190,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     int el = P.elapsed[envc];
     if (mv >= M) { p.x = p.y = far_away<RT>(); v.x = v.y = (RT)0; a.x = a.y = (RT)0; acc.x = acc.y = (RT)0; }  // group padding
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
+    const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
     if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
@@ -186,6 +222,12 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // drawing always (GPR_EAGER_NOISE=1 does that; tests compare the two). The branch is per wavefront: one uncertain lane
     // makes all 64 draw.
     const bool eager = P.eager_noise != 0;
+    constexpr uint32_t R = SHAPE == 0 ? 1u : 3u, S = 1u + 2u * R;  // normal pairs per qpos read / per mover per cycle
+    // box shape: wall sizes (BE:487, add_safety_offset=False), and how far a vertex can move under a noisy read: the centre by
+    // band_p, plus a rotation of at most 2*sqrt(3)*band_p rad (noise on the identity quaternion) times the half diagonal
+    const RT bw0 = (c + C.c_offset_wall) + (RT)0 * C.c_offset, bw1 = (c1 + C.c_offset_wall) + (RT)0 * C.c_offset;
+    const RT bdiag = Math<RT>::sqrt_(bw0 * bw0 + bw1 * bw1);
+    const RT band_b = C.band_p * ((RT)1 + (RT)3.5 * bdiag) + (RT)1e-6 * bdiag;
     const RT band_pair = (RT)2 * C.band_p;  // two movers, each off by up to band_p
     const R2<RT> dta{C.dt * a.x, C.dt * a.y};
     const RT vlim = C.v_max - C.band_v, vlim2 = vlim > (RT)0 ? vlim * vlim : (RT)-1;
@@ -204,7 +246,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 const RT t0 = v.x + C.dt * acc_tmp.x, t1 = v.y + C.dt * acc_tmp.y;
                 const RT lim = C.v_max - C.band_v;
                 const bool need = !(t0 * t0 + t1 * t1 < lim * lim) | (lim <= (RT)0);
-                if (eager | (__ballot(need) != 0ull)) vn = noisy<RT, true>(v, C.sig_v, key, 3u * (uint32_t)cyc);  // PL:430
+                if (eager | (__ballot(need) != 0ull)) vn = noisy<RT, true>(v, C.sig_v, key, S * (uint32_t)cyc);  // PL:430
             }
             if constexpr (JERK) {  // PL:437-440
                 R2<RT> vnext;
@@ -236,7 +278,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             if constexpr (NOISE) {
                 // the velocity reading only matters if the speed clamp can fire (PL:634): |v + dt*a| within band_v of v_max
                 if (eager | (__ballot(!(n2 < vlim2)) != 0ull)) {
-                    const R2<RT> n = rng_normal_pair<RT>(key, 3u * (uint32_t)cyc);  // PL:430
+                    const R2<RT> n = rng_normal_pair<RT>(key, S * (uint32_t)cyc);  // PL:430
                     nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
                     t.x += nv.x; t.y += nv.y;
                     n2 = t.x * t.x + t.y * t.y;
@@ -254,17 +296,38 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         }
         // BE:1888-1901: wall check and mover check, each on its own noisy position read
         bool w, hit;
-        if constexpr (NOISE) {
+        if constexpr (SHAPE == 1) {
+            const Pose<RT> q0{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0};
+            if constexpr (NOISE) {
+                bool unc;
+                w = live & !pos_valid_box<RT, true>(T, P, q0, bw0, bw1, band_b, &unc);
+                if (eager | (__ballot(live & unc) != 0ull)) {
+                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                    w = live & !pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr);
+                }
+                // no partner within the distance pre-filter (BE:411-414) even after two worst-case reads: no collision, no draw
+                bool near;
+                (void)box_pair_hit<RT, LPE>(q0, c, c1, (RT)2 * band_b, false, &near);
+                hit = false;
+                if (eager | (__ballot(live & near) != 0ull)) {
+                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
+                    hit = live & box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr);
+                }
+            } else {
+                w = live & !pos_valid_box<RT, false>(T, P, q0, bw0, bw1, (RT)0, nullptr);
+                hit = live & box_pair_hit<RT, LPE>(q0, c, c1, (RT)0, true, nullptr);
+            }
+        } else if constexpr (NOISE) {
             bool unc;
             w = live & !pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &unc);
             if (eager | (__ballot(live & unc) != 0ull)) {
-                const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
+                const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
                 w = live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
             }
             const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
             hit = live & (md <= pair_thr);  // BE:409, inclusive
             if (eager | (__ballot(live & (absr(md - pair_thr) <= pair_band)) != 0ull)) {
-                const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, 3u * (uint32_t)cyc + 2u);
+                const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
                 hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step);
             }
         } else {
@@ -288,7 +351,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     v.x = stored<ST, RT>(v.x); v.y = stored<ST, RT>(v.y);
     acc.x = stored<ST, RT>(acc.x); acc.y = stored<ST, RT>(acc.y);
 
-    Obs<RT> o = observe<ST, RT, LPE, NOISE>(P, key, 3u * (uint32_t)P.num_cycles, p, v, g, mc, wc, live);
+    Obs<RT> o = observe<ST, RT, LPE, NOISE>(P, key, S * (uint32_t)P.num_cycles, p, v, g, mc, wc, live);
     int el_new = reset_first ? el : el + 1;
     bool trunc = (P.max_episode_steps > 0) & (el_new >= P.max_episode_steps);  // gymnasium TimeLimit
     const bool done = (o.terminated | trunc) & !reset_first;
@@ -301,7 +364,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         }
         R2<RT> rp = p, rg = g;
         bool rwc, rmc;
-        Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL>(P, T, env_global, mv, mvc, live, need, c, rp, rg, rwc, rmc);
+        Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, rp, rg, rwc, rmc);
         if (need) {
             p = rp; g = rg;
             v = R2<RT>{(RT)0, (RT)0};
@@ -329,7 +392,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 // -----------------------------------------------------------------------------------------------------------------
 // reset (explicit): BE:1770-1833 for the envs selected by mask (all when mask == NULL)
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL>
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
 __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int M = P.M;
@@ -343,13 +406,13 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
     const int64_t env_global = P.env_id_offset + envc;
     const bool need = live_env & (P.mask ? (P.mask[envc] != 0) : true);
-    const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];
+    const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc], c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];
     R2<RT> p = load2<ST, RT>(P.pos, idx), g = load2<ST, RT>(P.goal, idx);
     if (mv >= M) p.x = p.y = far_away<RT>();
     if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
-    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL>(P, T, env_global, mv, mvc, live, need, c, p, g, wc, mc);
+    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, p, g, wc, mc);
     if (live & need) {
         const R2<RT> zero{(RT)0, (RT)0};
         store2<ST, RT>(P.pos, idx, p);
@@ -364,23 +427,25 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
 // -----------------------------------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL> static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) {
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
+static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) {
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
     const unsigned lds = FULL ? 0u : P.table_bytes;
     if (is_reset) {
-        hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL>), dim3(grid), dim3(BLOCK), lds, s, P);
+        hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     } else {
-        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL>), dim3(grid), dim3(BLOCK), lds, s, P);
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     }
     return hipGetLastError();
 }
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipError_t launch_one(bool is_reset, const KParams &P, hipStream_t s) {
+    if (P.c_shape != 0) return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 1>(is_reset, P, s);  // 'box' collision shape
     // the throughput-mode wall check has a table-free form for grids without holes (pos_valid_circle): separate kernels
     if constexpr (!Math<RT>::literal) {
-        if (P.layout_full) return launch_kernel<ST, RT, LPE, JERK, NOISE, true>(is_reset, P, s);
+        if (P.layout_full) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 0>(is_reset, P, s);
     }
-    return launch_kernel<ST, RT, LPE, JERK, NOISE, false>(is_reset, P, s);
+    return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 0>(is_reset, P, s);
 }
 template <typename ST, typename RT, int LPE> static hipError_t launch_flags(bool is_reset, const KParams &P, hipStream_t s) {
     const bool jerk = P.learn_jerk != 0, noise = P.noise != 0;

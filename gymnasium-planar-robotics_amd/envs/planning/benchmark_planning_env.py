@@ -128,6 +128,7 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
             self.min_goal_dist = 2 * (self.c_size + self.c_size_offset)
             assert np.ndim(self.min_goal_dist) == 0, 'the planning env needs one collision radius for all movers (PL:263,271)'
         else:
+            assert np.shape(self.c_size) == (2,), 'the planning env samples starts / goals from one (2,) box size for all movers'
             self.min_goal_dist = 2 * np.linalg.norm(self.c_size + self.c_size_offset, ord=2)
 
         if self._host_only:

@@ -503,13 +503,6 @@ typedef struct {
 
 static double q32(const gpro_env_cfg *cfg, double x) { return cfg->storage_f32 ? (double)(float)x : x; }
 
-static void make_qpos(int M, const double *xy, double *qpos) {
-    for (int i = 0; i < M; ++i) {
-        double *q = qpos + 7 * i;
-        q[0] = xy[2 * i]; q[1] = xy[2 * i + 1]; q[2] = 0.0; q[3] = 1.0; q[4] = q[5] = q[6] = 0.0;
-    }
-}
-
 /* noisy copy of M xy pairs: normal pair number q of each mover's stream (x <- n0, y <- n1) */
 static void noisy(const env_ctx *c, const uint32_t *keys, uint32_t q, int M, const double *xy, double sigma, double *out) {
     for (int i = 0; i < M; ++i) {
@@ -520,24 +513,47 @@ static void noisy(const env_ctx *c, const uint32_t *keys, uint32_t q, int M, con
     }
 }
 
-/* check_wall_collision(...).any() (BE:426-457) on xy positions */
-static int wall_any(const env_ctx *c, const double *xy, int add_safety, double *margin) {
+/* A noisy qpos read of every mover (BE:828: qpos + N(0, sigma) on all seven components). x,y take normal pair q; for the
+ * box shape the quaternion (1,0,0,0) takes pairs q+1 (w,x) and q+2 (y,z) -- the circle shape never looks at it, and
+ * nothing looks at z. The engine's draw numbering: reads_per_check() pairs per collision check. */
+static int reads_per_check(const env_ctx *c) { return c->cfg->lay.c_shape == 0 ? 1 : 3; }
+
+static void noisy_qpos(const env_ctx *c, const uint32_t *keys, uint32_t q, int M, const double *xy, double sigma, int with_noise,
+                       double *qpos) {
+    for (int i = 0; i < M; ++i) {
+        double *o = qpos + 7 * i;
+        o[0] = xy[2 * i]; o[1] = xy[2 * i + 1]; o[2] = 0.0; o[3] = 1.0; o[4] = o[5] = o[6] = 0.0;
+        if (with_noise && c->noise) {
+            double n0, n1;
+            gpro_rng_normal_pair(keys[i], q, &n0, &n1);
+            o[0] = xy[2 * i] + sigma * n0; o[1] = xy[2 * i + 1] + sigma * n1;
+            if (c->cfg->lay.c_shape != 0) {
+                gpro_rng_normal_pair(keys[i], q + 1u, &n0, &n1);
+                o[3] = 1.0 + sigma * n0; o[4] = 0.0 + sigma * n1;
+                gpro_rng_normal_pair(keys[i], q + 2u, &n0, &n1);
+                o[5] = 0.0 + sigma * n0; o[6] = 0.0 + sigma * n1;
+            }
+        } else {
+            o[0] = xy[2 * i] + sigma * 0.0; o[1] = xy[2 * i + 1] + sigma * 0.0;
+        }
+    }
+}
+
+/* check_wall_collision(...).any() (BE:426-457) */
+static int wall_any(const env_ctx *c, const double *qpos, int add_safety, double *margin) {
     const gpro_env_cfg *cfg = c->cfg;
     int M = cfg->num_movers, wall = 0;
     for (int i = 0; i < M; ++i) {
-        double q[7] = {xy[2 * i], xy[2 * i + 1], 0, 1, 0, 0, 0};
         double cs0 = cfg->c_size[2 * i] + cfg->lay.c_offset_wall + (double)(add_safety != 0) * cfg->lay.c_offset;
         double cs1 = cfg->c_size[2 * i + 1] + cfg->lay.c_offset_wall + (double)(add_safety != 0) * cfg->lay.c_offset;
         int above = 0;
-        int valid = qpos_valid_one(&cfg->lay, c->xc, c->yc, q, cs0, cs1, &above, margin);
+        int valid = qpos_valid_one(&cfg->lay, c->xc, c->yc, qpos + 7 * i, cs0, cs1, &above, margin);
         if (!valid) wall = 1; /* a mover above no tile is a wall collision in the engine (reference: AssertionError, BE:514) */
     }
     return wall;
 }
 
-static int pair_any(const env_ctx *c, const double *xy, int add_safety, double *margin) {
-    double qpos[GPRO_MAX_MOVERS * 7];
-    make_qpos(c->cfg->num_movers, xy, qpos);
+static int pair_any(const env_ctx *c, const double *qpos, int add_safety, double *margin) {
     return gpro_check_mover_collision(&c->cfg->lay, c->cfg->num_movers, qpos, c->cfg->c_size, add_safety, margin);
 }
 
@@ -584,8 +600,10 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
             double u = gpro_rng_uniform(ks[k >> 1], 2u * (uint32_t)trial + (uint32_t)d);
             xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:377 */
         }
-        int wall = wall_any(c, xy, 1, margin);  /* PL:379 add_safety_offset=True */
-        int coll = pair_any(c, xy, 1, margin);  /* PL:381-383 */
+        double qp[GPRO_MAX_MOVERS * 7];
+        noisy_qpos(c, ks, 0, M, xy, 0.0, 0, qp);
+        int wall = wall_any(c, qp, 1, margin);  /* PL:379 add_safety_offset=True */
+        int coll = pair_any(c, qp, 1, margin);  /* PL:381-383 */
         if (!coll && !wall) break;
     }
     memcpy(pos, xy, sizeof(double) * 2 * M);
@@ -595,7 +613,9 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
             double u = gpro_rng_uniform(kg[k >> 1], 2u * (uint32_t)trial + (uint32_t)d);
             xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:402 */
         }
-        int wall = wall_any(c, xy, 1, margin); /* PL:403-404 */
+        double qp[GPRO_MAX_MOVERS * 7];
+        noisy_qpos(c, kg, 0, M, xy, 0.0, 0, qp);
+        int wall = wall_any(c, qp, 1, margin); /* PL:403-404 */
         int ok = !wall;
         if (ok) {
             for (int i = 0; i < M && ok; ++i) for (int j = i + 1; j < M; ++j) { /* PL:407-413 */
@@ -610,12 +630,13 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
     memcpy(goal, xy, sizeof(double) * 2 * M);
     for (int k = 0; k < 2 * M; ++k) { vel[k] = 0.0; acc[k] = 0.0; } /* reload_model + mj_forward: v = 0, act = 0, qacc = 0 */
     *elapsed = 0;
-    double tmp[GPRO_MAX_MOVERS * 2];
-    noisy(c, kn, 0, M, pos, cfg->std_noise[0], tmp);
-    int wc = wall_any(c, tmp, 1, margin); /* BE:1799-1801 add_safety_offset=True */
-    noisy(c, kn, 1, M, pos, cfg->std_noise[0], tmp);
-    int mc = pair_any(c, tmp, 0, margin); /* BE:1803-1805 add_safety_offset=False */
-    observe(c, kn, 2, pos, vel, acc, goal, mc, wc, e, out, margin);
+    double qp[GPRO_MAX_MOVERS * 7];
+    const uint32_t R = (uint32_t)reads_per_check(c);
+    noisy_qpos(c, kn, 0, M, pos, cfg->std_noise[0], 1, qp);
+    int wc = wall_any(c, qp, 1, margin); /* BE:1799-1801 add_safety_offset=True */
+    noisy_qpos(c, kn, R, M, pos, cfg->std_noise[0], 1, qp);
+    int mc = pair_any(c, qp, 0, margin); /* BE:1803-1805 add_safety_offset=False */
+    observe(c, kn, 2u * R, pos, vel, acc, goal, mc, wc, e, out, margin);
     out->truncated[e] = 0;
 }
 
@@ -669,10 +690,11 @@ static void step_range(const env_ctx *c, int64_t e0, int64_t e1, uint64_t seed, 
         double a[GPRO_MAX_MOVERS * 2];
         for (int k = 0; k < 2 * M; ++k) a[k] = fmin(fmax(action[2 * M * e + k], -lim), lim);
         int wc = 0, mc = 0;
+        const uint32_t R = (uint32_t)reads_per_check(c), S = 1u + 2u * R; /* normal pairs drawn per mover per cycle */
         for (int cyc = 0; cyc < cfg->num_cycles; ++cyc) { /* BE:1879 */
             /* _mujoco_step_callback (PL:420-450) */
             double nv[GPRO_MAX_MOVERS * 2], u[GPRO_MAX_MOVERS * 2];
-            noisy(c, keys, 3u * (uint32_t)cyc, M, vel, cfg->std_noise[1], nv); /* PL:430 */
+            noisy(c, keys, S * (uint32_t)cyc, M, vel, cfg->std_noise[1], nv); /* PL:430 */
             for (int i = 0; i < M; ++i) {
                 double vals[2], ders[2];
                 if (cfg->learn_jerk) { /* PL:432-440 */
@@ -700,15 +722,15 @@ static void step_range(const env_ctx *c, int64_t e0, int64_t e1, uint64_t seed, 
                 vel[k] = vel[k] + dt * qacc;
                 pos[k] = pos[k] + dt * vel[k];
             }
-            double np_[GPRO_MAX_MOVERS * 2];
-            noisy(c, keys, 3u * (uint32_t)cyc + 1u, M, pos, cfg->std_noise[0], np_);
-            wc = wall_any(c, np_, 0, margin); /* BE:1888-1894 */
-            noisy(c, keys, 3u * (uint32_t)cyc + 2u, M, pos, cfg->std_noise[0], np_);
-            mc = pair_any(c, np_, 0, margin); /* BE:1895-1901 */
+            double qp[GPRO_MAX_MOVERS * 7];
+            noisy_qpos(c, keys, S * (uint32_t)cyc + 1u, M, pos, cfg->std_noise[0], 1, qp);
+            wc = wall_any(c, qp, 0, margin); /* BE:1888-1894 */
+            noisy_qpos(c, keys, S * (uint32_t)cyc + 1u + R, M, pos, cfg->std_noise[0], 1, qp);
+            mc = pair_any(c, qp, 0, margin); /* BE:1895-1901 */
             if (mc || wc) break;              /* BE:1904-1905 */
         }
         for (int k = 0; k < 2 * M; ++k) { pos[k] = q32(cfg, pos[k]); vel[k] = q32(cfg, vel[k]); acc[k] = q32(cfg, acc[k]); }
-        observe(c, keys, 3u * (uint32_t)cfg->num_cycles, pos, vel, acc, goal, mc, wc, e, out, margin);
+        observe(c, keys, S * (uint32_t)cfg->num_cycles, pos, vel, acc, goal, mc, wc, e, out, margin);
         elapsed_a[e] += 1;
         int trunc = cfg->max_episode_steps > 0 && elapsed_a[e] >= cfg->max_episode_steps; /* gymnasium TimeLimit */
         out->truncated[e] = (uint8_t)trunc;

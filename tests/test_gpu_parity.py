@@ -149,6 +149,10 @@ CONFIGS = [
     (np.ones((10, 10)), 16, {'num_cycles': 10}),
     (np.ones((6, 6)), 4, {'autoreset_mode': 'next_step'}),
     (np.ones((6, 6)), 5, {'autoreset_mode': 'disabled', 'max_episode_steps': 7}),
+    # 'box' collision shape: rotated-rectangle wall check (vertices, missing-corner tests) and rectangle-rectangle mover check
+    (np.ones((5, 5)), 3, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.002}}),
+    (HOLES, 4, {'collision_params': {'shape': 'box', 'size': np.array([0.06, 0.09]), 'offset_wall': 0.001}, 'std_noise': 0.0}),
+    (np.ones((4, 7)), 8, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775])}, 'learn_jerk': True, 'num_cycles': 20}),
 ]
 
 
@@ -290,9 +294,11 @@ def test_sharding_invariance_and_determinism(gpr):
 def test_lazy_noise_is_exact(gpr, monkeypatch):
     """The kernels skip a noise draw when no possible value of it could change the outcome of the comparison it feeds.
     GPR_EAGER_NOISE=1 (read at env creation) draws everything: both must produce bit-identical rollouts."""
-    for layout, M, prec in ((np.ones((6, 6)), 4, 'f32'), (HOLES, 3, 'f32'), (np.ones((5, 5)), 2, 'f64'), (np.ones((4, 6)), 2, 'f32')):
+    box = {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.001}
+    for layout, M, prec, cp in ((np.ones((6, 6)), 4, 'f32', None), (HOLES, 3, 'f32', None), (np.ones((5, 5)), 2, 'f64', None),
+                                (np.ones((4, 6)), 2, 'f32', None), (HOLES, 4, 'f32', box), (np.ones((4, 4)), 3, 'f64', box)):
         E = 2048 if prec == 'f32' else 256
-        kw = dict(num_envs=E, precision=prec, std_noise=np.array([2e-5, 1e-5, 0.0]), learn_jerk=(prec == 'f64'))
+        kw = dict(num_envs=E, precision=prec, std_noise=np.array([2e-5, 1e-5, 0.0]), learn_jerk=(prec == 'f64'), collision_params=cp)
         monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
         lazy = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
         monkeypatch.setenv('GPR_EAGER_NOISE', '1')
