@@ -6,6 +6,7 @@ __version__ = '0.1.0'
 from . import _native, distributed, spaces
 from .envs.basic_envs import VecBasicPlanarRoboticsEnv
 from .envs.planning.benchmark_planning_env import VecBenchmarkPlanningEnv
+from .envs.planning.parallel_planning_env import VecBenchmarkPlanningParallelEnv
 from .utils import geometry_2D_utils
 
-__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']
+__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'VecBenchmarkPlanningParallelEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']

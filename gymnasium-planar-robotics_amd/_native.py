@@ -17,7 +17,7 @@ PRECISION = {'f32': 0, 'f32_f64acc': 1, 'f64': 2}
 
 EXPORTS = (
     'gpr_version', 'gpr_last_error', 'gpr_create', 'gpr_destroy', 'gpr_bind_state', 'gpr_seed', 'gpr_reset', 'gpr_step',
-    'gpr_compute_reward', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
+    'gpr_compute_reward', 'gpr_agent_views', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
     'gpr_get_2D_rect_vertices', 'gpr_check_rectangles_intersect', 'gpr_ensure_max_dyn_val',
 )
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.gpr_reset.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_compute_reward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.gpr_agent_views.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gpr_qpos_is_valid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.gpr_check_mover_collision.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.gpr_check_line_segments_intersect.argtypes = [i64, vp, vp, vp, vp, vp, vp]

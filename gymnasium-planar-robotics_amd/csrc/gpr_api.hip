@@ -351,6 +351,19 @@ int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, co
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "reward kernel launch");
 }
 
+int gpr_agent_views(gpr_env *env, const void *observation_dev, const void *achieved_goal_dev, const void *desired_goal_dev,
+                    const void *reward_dev, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_agent_views: NULL handle");
+    if (!observation_dev || !achieved_goal_dev || !desired_goal_dev || !reward_dev || !agent_obs_dev || !agent_reward_dev)
+        return fail(env, GPR_E_INVALID, "gpr_agent_views: bad argument");
+    KParams P = make_params(env, nullptr, true);
+    const int obs_dim = env->cfg.num_movers * 2 * (env->cfg.learn_jerk ? 2 : 1);
+    hipError_t he = env->cfg.precision == GPR_PRECISION_F64
+                        ? launch_agent_views<double>(P, env->lpe, obs_dim, observation_dev, achieved_goal_dev, desired_goal_dev, reward_dev, agent_obs_dev, agent_reward_dev, as_stream(hip_stream))
+                        : launch_agent_views<float>(P, env->lpe, obs_dim, observation_dev, achieved_goal_dev, desired_goal_dev, reward_dev, agent_obs_dev, agent_reward_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(env, he, "agent views kernel launch");
+}
+
 int gpr_qpos_is_valid(gpr_env *env, int64_t n, const double *qpos_dev, const double *c_size_dev, int32_t add_safety_offset, int32_t *out_dev,
                       void *hip_stream) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_qpos_is_valid: NULL handle");

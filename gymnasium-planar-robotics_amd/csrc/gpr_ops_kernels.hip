@@ -123,6 +123,63 @@ template <typename ST> __global__ void __launch_bounds__(BLOCK) k_reward(const K
     if (terminated) terminated[b] = (uint8_t)((r == rs) | (r == -rs));
 }
 
+// per-agent views (include/gpr.h: gpr_agent_views): one lane per (env, mover); the other movers' columns arrive by lane
+// permutes inside the env group -- the "per-agent obs gather" is intra-wavefront, no memory round trip
+template <typename ST, int LPE, int D> struct AgentGather {
+    static __device__ __forceinline__ void run(ST px, ST py, ST vx, ST vy, int mv, int M, ST *row) {
+        if constexpr (D < LPE) {
+            const ST ox = rot<LPE, D>(px), oy = rot<LPE, D>(py), ovx = rot<LPE, D>(vx), ovy = rot<LPE, D>(vy);
+            const int j = (mv + D) & (LPE - 1);
+            if (j < M && mv < M) {
+                ST *dst = row + 6 + 4 * (j < mv ? j : j - 1);  // ascending j, skipping the agent itself
+                dst[0] = ox - px; dst[1] = oy - py; dst[2] = ovx - vx; dst[3] = ovy - vy;
+            }
+            AgentGather<ST, LPE, D + 1>::run(px, py, vx, vy, mv, M, row);
+        }
+    }
+};
+template <typename ST, int LPE>
+__global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_dim, const ST *obs, const ST *ag, const ST *dg, const ST *reward,
+                                                       ST *agent_obs, ST *agent_reward) {
+    const int M = P.M;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int mv = (int)(t & (LPE - 1));
+    const int64_t env = t / LPE;
+    const bool live = (env < P.E) & (mv < M);
+    const int64_t envc = env < P.E ? env : P.E - 1;
+    const int mvc = mv < M ? mv : M - 1;
+    const ST vx = obs[envc * obs_dim + 2 * mvc], vy = obs[envc * obs_dim + 2 * mvc + 1];
+    const ST px = ag[envc * 2 * M + 2 * mvc], py = ag[envc * 2 * M + 2 * mvc + 1];
+    const ST gx = dg[envc * 2 * M + 2 * mvc], gy = dg[envc * 2 * M + 2 * mvc + 1];
+    ST *row = agent_obs + (envc * M + mvc) * (int64_t)(4 * M + 2);
+    if (live) { row[0] = vx; row[1] = vy; row[2] = px; row[3] = py; row[4] = gx; row[5] = gy; }
+    AgentGather<ST, LPE, 1>::run(px, py, vx, vy, live ? mv : LPE, M, row);  // dead lanes write nothing (mv = LPE fails mv < M)
+    if (live) {
+        const double r = (double)reward[envc], rs = P.cd.reward_success, dx = (double)px - (double)gx, dy = (double)py - (double)gy;
+        const bool shared = (r == rs) | (r == -rs);  // PL:529-531
+        agent_reward[envc * M + mvc] = shared ? (ST)r : (ST)(sqrt(dx * dx + dy * dy) <= P.cd.thr ? 0.0 : -1.0);
+    }
+}
+template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, const void *obs, const void *ag, const void *dg,
+                                                     const void *reward, void *agent_obs, void *agent_reward, hipStream_t s) {
+    const unsigned grid = grid_for(P.E * lpe);
+    auto a = [&](auto K) {
+        hipLaunchKernelGGL(K, dim3(grid), dim3(BLOCK), 0, s, P, obs_dim, static_cast<const ST *>(obs), static_cast<const ST *>(ag),
+                           static_cast<const ST *>(dg), static_cast<const ST *>(reward), static_cast<ST *>(agent_obs), static_cast<ST *>(agent_reward));
+    };
+    switch (lpe) {
+        case 1: a(k_agent_views<ST, 1>); break;
+        case 2: a(k_agent_views<ST, 2>); break;
+        case 4: a(k_agent_views<ST, 4>); break;
+        case 8: a(k_agent_views<ST, 8>); break;
+        case 16: a(k_agent_views<ST, 16>); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+template hipError_t launch_agent_views<float>(const KParams &, int, int, const void *, const void *, const void *, const void *, void *, void *, hipStream_t);
+template hipError_t launch_agent_views<double>(const KParams &, int, int, const void *, const void *, const void *, const void *, void *, void *, hipStream_t);
+
 hipError_t launch_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2, uint8_t *out, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_segments, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, p1, p2, q1, q2, out);
     return hipGetLastError();

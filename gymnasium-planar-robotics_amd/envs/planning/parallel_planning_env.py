@@ -1,0 +1,89 @@
+"""``VecBenchmarkPlanningParallelEnv``: a PettingZoo-``ParallelEnv``-shaped view of ``VecBenchmarkPlanningEnv`` -- one agent per
+mover, every per-agent array batched over ``num_envs``.
+
+What the reference offers here is ``BasicPlanarRoboticsMultiAgentEnv`` (gymnasium_planar_robotics/envs/basic_envs.py:1629-1693):
+an empty PettingZoo shell whose only content is ``agents = possible_agents = mover_names`` (``mover_0`` ...), and which does not
+construct at the reference's HEAD. There is therefore **no reference behaviour to match**: the physics, termination and
+truncation are exactly those of the single-agent env (one fused kernel launch), and the per-agent observation / reward layout is
+this engine's own definition (include/gpr.h, ``gpr_agent_views``):
+
+* ``observations[agent]`` ``[E, 4M+2]``: own velocity, own position, own goal, then for every other mover in ascending index its
+  position and velocity relative to the agent (a lane-permute gather inside the env's wavefront group, no extra memory pass);
+* ``rewards[agent]`` ``[E]``: the env reward of PL:519-531 split per agent: -50 / +50 for every agent on collision / joint
+  success, otherwise -1 while the agent's own goal is not reached, 0 once it is (summing to the single-agent reward);
+* ``terminations`` / ``truncations`` / ``infos``: the env's, shared by every agent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _native, spaces
+from .benchmark_planning_env import VecBenchmarkPlanningEnv
+
+
+class VecBenchmarkPlanningParallelEnv:
+    metadata = {'name': 'VecBenchmarkPlanningParallelEnv', 'render_modes': []}
+
+    def __init__(self, *args, **kwargs) -> None:
+        self.env = VecBenchmarkPlanningEnv(*args, **kwargs)
+        e = self.env
+        self.possible_agents = list(e.mover_names)  # BE:1692-1693
+        self.agents = list(self.possible_agents)
+        self.num_envs, self.num_movers = e.num_envs, e.num_movers
+        M = self.num_movers
+        self.agent_obs_dim = 4 * M + 2
+        lim = e.j_max if e.learn_jerk else e.a_max
+        self._obs_space = spaces.Box(-np.inf, np.inf, shape=(self.agent_obs_dim,), dtype=np.float64)
+        self._act_space = spaces.Box(-lim, lim, shape=(2,), dtype=np.float64)
+        if not e._host_only:
+            self._agent_obs = torch.zeros(e.num_envs, M, self.agent_obs_dim, dtype=e.dtype, device=e.device)
+            self._agent_reward = torch.zeros(e.num_envs, M, dtype=e.dtype, device=e.device)
+            self._action = torch.zeros(e.num_envs, 2 * M, dtype=e.dtype, device=e.device)
+
+    def observation_space(self, agent: str) -> spaces.Box:
+        return self._obs_space
+
+    def action_space(self, agent: str) -> spaces.Box:
+        return self._act_space
+
+    def _views(self):
+        e = self.env
+        with torch.cuda.device(e.device):
+            _native.check(e._lib.gpr_agent_views(e._handle, e._obs['observation'].data_ptr(), e._obs['achieved_goal'].data_ptr(),
+                                                 e._obs['desired_goal'].data_ptr(), e._reward.data_ptr(), self._agent_obs.data_ptr(),
+                                                 self._agent_reward.data_ptr(), e._stream()), e._handle)
+        obs = {a: self._agent_obs[:, i, :] for i, a in enumerate(self.agents)}
+        rew = {a: self._agent_reward[:, i] for i, a in enumerate(self.agents)}
+        return obs, rew
+
+    def reset(self, seed: int | None = None, options: dict | None = None):
+        _, info = self.env.reset(seed=seed, options=options)
+        obs, _ = self._views()
+        return obs, {a: info for a in self.agents}
+
+    def step(self, actions: dict[str, torch.Tensor] | torch.Tensor):
+        """``actions``: dict agent -> ``[E, 2]`` tensor (every agent must act: the env is fully cooperative and simultaneous),
+        or one ``[E, M, 2]`` / ``[E, 2M]`` tensor."""
+        e = self.env
+        if isinstance(actions, dict):
+            assert set(actions) == set(self.agents), 'every agent must supply an action'
+            act = self._action.view(e.num_envs, self.num_movers, 2)
+            for i, a in enumerate(self.agents):
+                act[:, i, :] = torch.as_tensor(actions[a], device=e.device).to(e.dtype)
+            action = self._action
+        else:
+            action = torch.as_tensor(actions, device=e.device).to(e.dtype).reshape(e.num_envs, 2 * self.num_movers)
+        _, _, terminated, truncated, info = e.step(action)
+        obs, rew = self._views()
+        return obs, rew, {a: terminated for a in self.agents}, {a: truncated for a in self.agents}, {a: info for a in self.agents}
+
+    def state(self) -> torch.Tensor:
+        """global state ``[E, 6M]``: velocities, positions, goals (the single-agent observation dict, concatenated)"""
+        o = self.env._obs
+        return torch.cat([o['observation'], o['achieved_goal'], o['desired_goal']], dim=1)
+
+    def close(self) -> None:
+        self.env.close()

@@ -123,6 +123,17 @@ int gpr_qpos_is_valid(gpr_env *env, int64_t n, const double *qpos_dev, const dou
 int gpr_check_mover_collision(gpr_env *env, int64_t batch, const double *qpos_dev, const double *c_size_dev,
                               int32_t add_safety_offset, uint8_t *out_dev, void *hip_stream);
 
+/* Per-agent views for a PettingZoo-parallel layer. The reference's BasicPlanarRoboticsMultiAgentEnv (BE:1629-1693) only names
+ * one agent per mover ("mover_i", BE:1692-1693) and defines no multi-agent observation or reward, so this layout is the
+ * engine's own (no reference parity to claim):
+ *   agent_obs_dev    [E][M][4M+2] real: own velocity (2), own position (2), own goal (2), then for every OTHER mover j in
+ *                    ascending j: position of j relative to the agent (2), velocity of j relative to the agent (2)
+ *   agent_reward_dev [E][M] real: the env reward of PL:519-531 split per agent -- -50 / +50 for every agent on collision /
+ *                    success, otherwise -1 for an agent whose own goal is not reached (PL:524) and 0 for one that is
+ * Inputs are the outputs of gpr_step / gpr_reset (observation [E][obs_dim], achieved_goal, desired_goal [E][2M], reward [E]). */
+int gpr_agent_views(gpr_env *env, const void *observation_dev, const void *achieved_goal_dev, const void *desired_goal_dev,
+                    const void *reward_dev, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream);
+
 /* ---- stateless operators (f64, device pointers) --------------------------------------------------------------- */
 /* geometry_2D_utils.check_line_segments_intersect (GEO:9-69): p1,p2,q1,q2 [n][2]; out [n] bytes */
 int gpr_check_line_segments_intersect(int64_t n, const double *p1_dev, const double *p2_dev, const double *q1_dev,

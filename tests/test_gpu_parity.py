@@ -322,6 +322,41 @@ def test_lazy_noise_is_exact(gpr, monkeypatch):
         lazy.close(); eager.close()
 
 
+@pytest.mark.parametrize('M,precision', [(1, 'f32'), (3, 'f64'), (4, 'f32'), (8, 'f32'), (16, 'f32')])
+def test_parallel_env_agent_views(gpr, M, precision):
+    """PettingZoo-parallel layer: the per-agent gather kernel against a plain NumPy statement of its documented layout
+    (engine-defined, the reference has no multi-agent semantics), and consistency with the single-agent outputs."""
+    E = 200
+    n = max(6, int(np.ceil(np.sqrt(M))) * 3)
+    penv = gpr.VecBenchmarkPlanningParallelEnv(np.ones((n, n)), M, num_envs=E, precision=precision)
+    assert penv.agents == [f'mover_{i}' for i in range(M)] and penv.observation_space('mover_0').shape == (4 * M + 2,)
+    obs, infos = penv.reset(seed=2)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for step in range(25):
+        act = {a: (torch.rand(E, 2, device='cuda', generator=g) * 20 - 10) for a in penv.agents}
+        obs, rew, term, trunc, infos = penv.step(act)
+        e = penv.env
+        v = e._obs['observation'].double().cpu().numpy().reshape(E, M, 2); p = e._obs['achieved_goal'].double().cpu().numpy().reshape(E, M, 2)
+        gl = e._obs['desired_goal'].double().cpu().numpy().reshape(E, M, 2); r = e._reward.double().cpu().numpy()
+        tot = np.zeros(E)
+        for i, a in enumerate(penv.agents):
+            exp = [v[:, i], p[:, i], gl[:, i]]
+            for j in range(M):
+                if j != i:
+                    exp += [p[:, j] - p[:, i], v[:, j] - v[:, i]]
+            exp = np.concatenate(exp, axis=1)
+            got = obs[a].double().cpu().numpy()
+            assert np.abs(got - exp).max() < (1e-12 if precision == 'f64' else 1e-6), (step, a)
+            shared = (r == 50) | (r == -50)
+            own = np.where(np.linalg.norm(p[:, i] - gl[:, i], axis=1) <= 0.1, 0.0, -1.0)
+            assert np.array_equal(rew[a].double().cpu().numpy(), np.where(shared, r, own))
+            tot += np.where(shared, 0.0, own)
+            assert term[a] is term['mover_0'] and torch.equal(term[a], e._terminated.view(torch.bool))
+        assert np.array_equal(tot[~shared], r[~shared])  # the per-agent rewards add up to the env reward (PL:530)
+    assert penv.state().shape == (E, 6 * M)
+    penv.close()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # full benchmark size: size-independent properties
 # ----------------------------------------------------------------------------------------------------------------------
