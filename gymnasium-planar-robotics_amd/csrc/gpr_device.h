@@ -549,22 +549,27 @@ __device__ __forceinline__ bool box_pair_hit(const Pose<RT> &q, RT c0, RT c1, RT
 // equal radii, and reproduced as is for unequal ones.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename RT, int LPE, int D> struct PairSweep {
-    static __device__ __forceinline__ void run(RT x, RT y, RT &best) {
-        if constexpr (D <= LPE / 2 && D >= 1 && LPE > 1) {
-            RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
-            RT d2 = dx * dx + dy * dy;
-            RT m = Math<RT>::literal ? Math<RT>::sqrt_(d2) : d2;
-            best = m < best ? m : best;
-            PairSweep<RT, LPE, D + 1>::run(x, y, best);
+    // smallest of the pair distances at rotation D .. LPE/2
+    static __device__ __forceinline__ RT run(RT x, RT y) {
+        const RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
+        const RT d2 = dx * dx + dy * dy;
+        const RT m = Math<RT>::literal ? Math<RT>::sqrt_(d2) : d2;
+        if constexpr (D < LPE / 2) {
+            const RT rest = PairSweep<RT, LPE, D + 1>::run(x, y);
+            return rest < m ? rest : m;
+        } else {
+            return m;
         }
     }
 };
 // Lanes that pad an env group (mover index >= M) are parked at FAR_AWAY so that no live mover ever sees them as a partner.
 template <typename RT> __device__ __forceinline__ RT far_away() { return sizeof(RT) == 8 ? (RT)1e150 : (RT)1e18f; }
 template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_dist(RT x, RT y) {
-    RT best = Math<RT>::inf();
-    PairSweep<RT, LPE, 1>::run(x, y, best);
-    return best;
+    if constexpr (LPE == 1) {
+        return Math<RT>::inf();
+    } else {
+        return PairSweep<RT, LPE, 1>::run(x, y);
+    }
 }
 // compare a pair_min_dist result against a distance limit: <= (collision, BE:409) or < (goal spacing, PL:409)
 template <typename RT> __device__ __forceinline__ bool dist_le(RT m, RT lim) { return Math<RT>::literal ? (m <= lim) : (m <= lim * lim); }

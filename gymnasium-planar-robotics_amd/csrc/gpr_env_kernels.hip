@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const bool reset_first = (P.autoreset == 2) & (el < 0);  // next-step autoreset: this call only resets the env
     // per-env decisions are kept as wave masks (one bit per lane, identical within an env group): scalar registers
     unsigned long long frozen_m = __ballot(reset_first), wc_m = 0ull, mc_m = 0ull;
+    const unsigned long long live_m = __ballot(live);
     uint32_t key = 0u;
     if constexpr (NOISE) key = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)mvc);
 
@@ -294,49 +295,50 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 p.x = p0.x + dp.x; p.y = p0.y + dp.y;
             }
         }
-        // BE:1888-1901: wall check and mover check, each on its own noisy position read
-        bool w, hit;
+        // BE:1888-1901: wall check and mover check, each on its own noisy position read. Results are kept as wave masks
+        // (one bit per lane, straight out of the vector compares) and restricted to live, unfrozen lanes with scalar ALU ops.
+        unsigned long long wraw, hraw;
         if constexpr (SHAPE == 1) {
             const Pose<RT> q0{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0};
             if constexpr (NOISE) {
                 bool unc;
-                w = live & !pos_valid_box<RT, true>(T, P, q0, bw0, bw1, band_b, &unc);
-                if (eager | (__ballot(live & unc) != 0ull)) {
+                wraw = __ballot(!pos_valid_box<RT, true>(T, P, q0, bw0, bw1, band_b, &unc));
+                if (eager | ((__ballot(unc) & live_m) != 0ull)) {
                     const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
-                    w = live & !pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr);
+                    wraw = __ballot(!pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr));
                 }
                 // no partner within the distance pre-filter (BE:411-414) even after two worst-case reads: no collision, no draw
                 bool near;
                 (void)box_pair_hit<RT, LPE>(q0, c, c1, (RT)2 * band_b, false, &near);
-                hit = false;
-                if (eager | (__ballot(live & near) != 0ull)) {
+                hraw = 0ull;
+                if (eager | ((__ballot(near) & live_m) != 0ull)) {
                     const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
-                    hit = live & box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr);
+                    hraw = __ballot(box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr));
                 }
             } else {
-                w = live & !pos_valid_box<RT, false>(T, P, q0, bw0, bw1, (RT)0, nullptr);
-                hit = live & box_pair_hit<RT, LPE>(q0, c, c1, (RT)0, true, nullptr);
+                wraw = __ballot(!pos_valid_box<RT, false>(T, P, q0, bw0, bw1, (RT)0, nullptr));
+                hraw = __ballot(box_pair_hit<RT, LPE>(q0, c, c1, (RT)0, true, nullptr));
             }
         } else if constexpr (NOISE) {
             bool unc;
-            w = live & !pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &unc);
-            if (eager | (__ballot(live & unc) != 0ull)) {
+            wraw = __ballot(!pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &unc));
+            if (eager | ((__ballot(unc) & live_m) != 0ull)) {
                 const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
-                w = live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
+                wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step));
             }
             const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
-            hit = live & (md <= pair_thr);  // BE:409, inclusive
-            if (eager | (__ballot(live & (absr(md - pair_thr) <= pair_band)) != 0ull)) {
+            hraw = __ballot(md <= pair_thr);  // BE:409, inclusive
+            if (eager | ((__ballot(absr(md - pair_thr) <= pair_band) & live_m) != 0ull)) {
                 const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
-                hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step);
+                hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
             }
         } else {
-            w = live & !pos_valid_circle<RT, FULL>(T, P, p.x, p.y, cw_step);
-            hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(p.x, p.y), C.max_csum_step);
+            wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, p.x, p.y, cw_step));
+            hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(p.x, p.y), C.max_csum_step));
         }
         // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle.
         // wc_m / mc_m collect the raw per-lane hits of not-yet-frozen envs; only the freeze decision needs the per-env OR now.
-        const unsigned long long wb = __ballot(w) & ~frozen_m, mb = __ballot(hit) & ~frozen_m;
+        const unsigned long long wb = wraw & live_m & ~frozen_m, mb = hraw & live_m & ~frozen_m;
         wc_m |= wb;
         mc_m |= mb;
         frozen_m |= group_or<LPE>(wb | mb);
