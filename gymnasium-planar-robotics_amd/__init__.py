@@ -5,8 +5,9 @@ __version__ = '0.1.0'
 
 from . import _native, distributed, spaces
 from .envs.basic_envs import VecBasicPlanarRoboticsEnv
+from .envs.manipulation.benchmark_pushing_env import VecBenchmarkPushingEnv
 from .envs.planning.benchmark_planning_env import VecBenchmarkPlanningEnv
 from .envs.planning.parallel_planning_env import VecBenchmarkPlanningParallelEnv
 from .utils import geometry_2D_utils
 
-__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'VecBenchmarkPlanningParallelEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']
+__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'VecBenchmarkPlanningParallelEnv', 'VecBenchmarkPushingEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']

@@ -17,7 +17,7 @@ PRECISION = {'f32': 0, 'f32_f64acc': 1, 'f64': 2}
 
 EXPORTS = (
     'gpr_version', 'gpr_last_error', 'gpr_create', 'gpr_destroy', 'gpr_bind_state', 'gpr_seed', 'gpr_reset', 'gpr_step',
-    'gpr_compute_reward', 'gpr_agent_views', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
+    'gpr_compute_reward', 'gpr_agent_views', 'gpr_push_configure', 'gpr_push_reset', 'gpr_push_step', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
     'gpr_get_2D_rect_vertices', 'gpr_check_rectangles_intersect', 'gpr_ensure_max_dyn_val',
 )
 
@@ -45,6 +45,17 @@ class GprStepOut(C.Structure):
                 ('reward_dev', C.c_void_p), ('terminated_dev', C.c_void_p), ('truncated_dev', C.c_void_p), ('is_success_dev', C.c_void_p),
                 ('mover_collision_dev', C.c_void_p), ('wall_collision_dev', C.c_void_p), ('final_observation_dev', C.c_void_p),
                 ('final_achieved_goal_dev', C.c_void_p), ('final_desired_goal_dev', C.c_void_p)]
+
+
+class GprPushParams(C.Structure):
+    _fields_ = [('mover_mass', C.c_double), ('mover_half_size', C.c_double * 2), ('object_half_size', C.c_double), ('object_mass', C.c_double),
+                ('object_damping', C.c_double), ('friction_tile', C.c_double), ('friction_contact', C.c_double),
+                ('friction_torsional', C.c_double), ('gravity', C.c_double), ('rot_stiffness', C.c_double), ('contact_timeconst', C.c_double),
+                ('object_noise', C.c_double), ('min_mo_dist', C.c_double), ('obj_min_xy', C.c_double * 2), ('obj_max_xy', C.c_double * 2)]
+
+
+class GprPushState(C.Structure):
+    _fields_ = [('mover_rot_dev', C.c_void_p), ('object_dev', C.c_void_p)]
 
 
 class GprError(RuntimeError):
@@ -81,6 +92,9 @@ def load() -> C.CDLL:
     lib.gpr_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_compute_reward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.gpr_agent_views.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gpr_push_configure.argtypes = [vp, C.POINTER(GprPushParams), C.POINTER(GprPushState)]
+    lib.gpr_push_reset.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
+    lib.gpr_push_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_qpos_is_valid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.gpr_check_mover_collision.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.gpr_check_line_segments_intersect.argtypes = [i64, vp, vp, vp, vp, vp, vp]

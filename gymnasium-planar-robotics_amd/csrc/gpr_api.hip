@@ -35,6 +35,10 @@ struct gpr_env {
     bool bound = false;
     uint64_t seed = 0, tick = 0;
     int lpe = 1;
+    bool push_ready = false;
+    PushCst<float> push_f{};
+    PushCst<double> push_d{};
+    PushPtrs push_ptrs{};
     mutable std::string err;
 };
 
@@ -217,6 +221,37 @@ int launch_env(gpr_env *e, bool is_reset, const KParams &P, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+template <typename RT> void fill_push(const gpr_env &e, const gpr_push_params &pp, PushCst<RT> &q) {
+    const double dt = e.cfg.cycle_time;
+    const double ax = pp.mover_half_size[0], ay = pp.mover_half_size[1], h = pp.object_half_size;
+    const double Im = pp.mover_mass * (ax * ax + ay * ay) / 3.0, Io = pp.object_mass * (2.0 * h * h) / 3.0;
+    const double inv_mo = 1.0 / pp.object_mass, inv_Io = 1.0 / Io;
+    q.inv_mm = (RT)(1.0 / pp.mover_mass); q.inv_mo = (RT)inv_mo; q.inv_Im = (RT)(1.0 / Im); q.inv_Io = (RT)inv_Io;
+    q.ax = (RT)ax; q.ay = (RT)ay; q.h = (RT)h;
+    q.Kr = (RT)pp.rot_stiffness; q.Dr = (RT)(2.0 * std::sqrt(pp.rot_stiffness * pp.mover_mass));
+    q.damp_lin = (RT)(1.0 / (1.0 + dt * pp.object_damping * inv_mo)); q.damp_rot_den = (RT)(1.0 + dt * pp.object_damping * inv_Io);
+    q.fric_dv = (RT)(pp.friction_tile * pp.gravity * dt);
+    q.fric_dw = (RT)(pp.friction_torsional * pp.object_mass * pp.gravity * inv_Io * dt);
+    q.mu = (RT)pp.friction_contact; q.tc = (RT)pp.contact_timeconst;
+    q.obj_noise = (RT)pp.object_noise; q.min_mo_dist = (RT)pp.min_mo_dist;
+    q.omin_x = (RT)pp.obj_min_xy[0]; q.omin_y = (RT)pp.obj_min_xy[1]; q.omax_x = (RT)pp.obj_max_xy[0]; q.omax_y = (RT)pp.obj_max_xy[1];
+}
+
+int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s) {
+    hipError_t he;
+    switch (env->cfg.precision) {
+        case GPR_PRECISION_F32:
+            he = env->cfg.learn_jerk ? launch_push<float, double>(is_reset, P, env->push_d, env->push_ptrs, s)
+                                     : launch_push<float, float>(is_reset, P, env->push_f, env->push_ptrs, s);
+            break;
+        case GPR_PRECISION_F32_F64ACC: he = launch_push<float, double>(is_reset, P, env->push_d, env->push_ptrs, s); break;
+        default: he = launch_push<double, double>(is_reset, P, env->push_d, env->push_ptrs, s); break;
+    }
+    return he == hipSuccess ? GPR_OK : fail_hip(env, he, is_reset ? "push reset kernel launch" : "push step kernel launch");
+}
+}  // namespace
+
 extern "C" {
 
 const char *gpr_version(void) { return "gpr-hip 0.1 (gfx950; rng gpr-rng-v1; one lane per mover)"; }
@@ -362,6 +397,46 @@ int gpr_agent_views(gpr_env *env, const void *observation_dev, const void *achie
                         ? launch_agent_views<double>(P, env->lpe, obs_dim, observation_dev, achieved_goal_dev, desired_goal_dev, reward_dev, agent_obs_dev, agent_reward_dev, as_stream(hip_stream))
                         : launch_agent_views<float>(P, env->lpe, obs_dim, observation_dev, achieved_goal_dev, desired_goal_dev, reward_dev, agent_obs_dev, agent_reward_dev, as_stream(hip_stream));
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "agent views kernel launch");
+}
+
+int gpr_push_configure(gpr_env *env, const gpr_push_params *pp, const gpr_push_state *st) {
+    if (!env || !pp || !st) return fail(env, GPR_E_INVALID, "gpr_push_configure: NULL argument");
+    if (env->cfg.num_movers != 1 || env->cfg.c_shape != GPR_SHAPE_CIRCLE)
+        return fail(env, GPR_E_INVALID, "gpr_push_configure: BenchmarkPushingEnv has one mover with a circular collision shape (PU:195-196)");
+    if (!(pp->mover_mass > 0) || !(pp->object_mass > 0) || !(pp->object_half_size > 0) || !(pp->mover_half_size[0] > 0) ||
+        !(pp->mover_half_size[1] > 0) || !(pp->contact_timeconst > 0) || !(pp->object_damping >= 0) || !(pp->gravity >= 0))
+        return fail(env, GPR_E_INVALID, "gpr_push_configure: masses, sizes and the contact time constant must be positive");
+    if (!st->mover_rot_dev || !st->object_dev) return fail(env, GPR_E_INVALID, "gpr_push_configure: state pointers must be set");
+    fill_push<float>(*env, *pp, env->push_f);
+    fill_push<double>(*env, *pp, env->push_d);
+    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev};
+    env->push_ready = true;
+    return GPR_OK;
+}
+
+int gpr_push_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_push_reset: NULL handle");
+    if (!env->bound || !env->push_ready) return fail(env, GPR_E_UNBOUND, "gpr_push_reset: call gpr_bind_state and gpr_push_configure first");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    KParams P = make_params(env, out, false);
+    P.mask = mask_dev;
+    rc = push_launch(env, true, P, as_stream(hip_stream));
+    if (rc == GPR_OK) env->tick += 1;
+    return rc;
+}
+
+int gpr_push_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_push_step: NULL handle");
+    if (!env->bound || !env->push_ready) return fail(env, GPR_E_UNBOUND, "gpr_push_step: call gpr_bind_state and gpr_push_configure first");
+    if (!action_dev) return fail(env, GPR_E_INVALID, "gpr_push_step: action is NULL");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    KParams P = make_params(env, out, false);
+    P.action = action_dev;
+    rc = push_launch(env, false, P, as_stream(hip_stream));
+    if (rc == GPR_OK) env->tick += 1;
+    return rc;
 }
 
 int gpr_qpos_is_valid(gpr_env *env, int64_t n, const double *qpos_dev, const double *c_size_dev, int32_t add_safety_offset, int32_t *out_dev,

@@ -52,6 +52,19 @@ struct KParams {
     uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
     void *final_obs, *final_ag, *final_dg;
 };
+// BenchmarkPushingEnv additions (include/gpr.h: gpr_push_params), in the compute type
+template <typename RT> struct PushCst {
+    RT inv_mm, inv_mo, inv_Im, inv_Io;  // inverse masses / planar inertias of mover and object
+    RT ax, ay, h;                       // half sizes
+    RT Kr, Dr;                          // yaw impedance: stiffness, damping 2 sqrt(K m) (IMP:42-47)
+    RT damp_lin, damp_rot_den;          // 1 / (1 + dt d / m) and (1 + dt d / I): implicit joint damping (PU:335)
+    RT fric_dv, fric_dw;                // velocity lost per cycle to tile friction: mu g dt, torsional
+    RT mu, tc;                          // contact friction, contact time constant (penetration recovery)
+    RT obj_noise, min_mo_dist, omin_x, omin_y, omax_x, omax_y;
+};
+struct PushPtrs {
+    void *mover_rot, *object;
+};
 template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
 template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }
 template <> __host__ __device__ __forceinline__ const Cst<double> &cst<double>(const KParams &P) { return P.cd; }
@@ -141,6 +154,16 @@ template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32
     const double rad = sqrt(-2.0 * log(u1));
     const double ang = 6.283185307179586476925286766559 * u2;
     return R2<double>{rad * cos(ang), rad * sin(ang)};
+}
+
+// a noisy 2-vector reading: value + sigma * N(0,1) per component (BE:828,841), from normal pair q of the lane's stream
+template <typename RT, bool NOISE> __device__ __forceinline__ R2<RT> noisy(R2<RT> v, RT sigma, uint32_t key, uint32_t q) {
+    if constexpr (NOISE) {
+        R2<RT> n = rng_normal_pair<RT>(key, q);
+        return R2<RT>{v.x + sigma * n.x, v.y + sigma * n.y};  // BE:828,841: value + N(0, sigma)
+    } else {
+        return v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

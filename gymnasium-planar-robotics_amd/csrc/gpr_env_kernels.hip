@@ -11,15 +11,6 @@
 
 namespace gpr {
 
-template <typename RT, bool NOISE> __device__ __forceinline__ R2<RT> noisy(R2<RT> v, RT sigma, uint32_t key, uint32_t q) {
-    if constexpr (NOISE) {
-        R2<RT> n = rng_normal_pair<RT>(key, q);
-        return R2<RT>{v.x + sigma * n.x, v.y + sigma * n.y};  // BE:828,841: value + N(0, sigma)
-    } else {
-        return v;
-    }
-}
-
 // a noisy qpos read for the box shape (BE:828 perturbs all seven components): x,y take normal pair q, the identity quaternion
 // takes pairs q+1 (w,x) and q+2 (y,z); z is never looked at
 template <typename RT, bool NOISE> __device__ __forceinline__ Pose<RT> noisy_pose(R2<RT> p, RT sigma, uint32_t key, uint32_t q) {

@@ -10,6 +10,9 @@ template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, 
 template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, const void *obs, const void *ag, const void *dg,
                                                      const void *reward, void *agent_obs, void *agent_reward, hipStream_t s);
 
+// BenchmarkPushingEnv kernels (gpr_push_kernels.hip)
+template <typename ST, typename RT> hipError_t launch_push(bool is_reset, const KParams &P, const PushCst<RT> &Q, const PushPtrs &X, hipStream_t s);
+
 // stand-alone f64 operators (gpr_ops_kernels.hip)
 hipError_t launch_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2, uint8_t *out, hipStream_t s);
 hipError_t launch_rect_vertices(int64_t n, const double *qpos, const double *size, double *out, hipStream_t s);

@@ -134,6 +134,42 @@ int gpr_check_mover_collision(gpr_env *env, int64_t batch, const double *qpos_de
 int gpr_agent_views(gpr_env *env, const void *observation_dev, const void *achieved_goal_dev, const void *desired_goal_dev,
                     const void *reward_dev, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream);
 
+/* ---- BenchmarkPushingEnv (gymnasium_planar_robotics/envs/manipulation/benchmark_pushing_env.py, "PU") -----------------
+ * One mover pushes one box over 3x3 tiles. The handle is created by gpr_create with num_movers = 1, a 3x3 layout and the
+ * 'circle' collision shape (PU:195-196); gpr_push_configure adds the object. Pinned by the reference: mover control and
+ * clamping (PU:419-448), observation / reward / terminated / info (PU:457-607), reset sampling (PU:373-417), wall check.
+ * NOT pinned ("parity unpinned"): contact dynamics -- the reference delegates them to MuJoCo, which this pipeline cannot
+ * run and which no reference test exercises; the kernels integrate the engine's own planar rigid-body model gpr-push-v1
+ * (DESIGN.md): 3-DoF boxes, SAT contact, sequential impulses with Coulomb friction, tile friction, joint damping (PU:335),
+ * impedance hold of the mover's yaw (PU:261-267). */
+typedef struct {
+    double mover_mass;          /* mover_params['mass'] (BE:230) */
+    double mover_half_size[2];  /* mover_params['size'][:2] (BE:250) */
+    double object_half_size;    /* PU:173 */
+    double object_mass;         /* PU:175 */
+    double object_damping;      /* PU:335 */
+    double friction_tile, friction_contact, friction_torsional; /* MuJoCo defaults: 1, 1, 0.005 */
+    double gravity;             /* 9.81 */
+    double rot_stiffness;       /* PU:266 */
+    double contact_timeconst;   /* MuJoCo default solref[0] = 0.02 */
+    double object_noise;        /* PU:178 */
+    double min_mo_dist;         /* PU:279-288 */
+    double obj_min_xy[2], obj_max_xy[2]; /* PU:257-258 */
+} gpr_push_params;
+
+/* extra state, DEVICE: mover_rot [E][2] = (yaw, yaw rate); object [E][6] = (x, y, yaw, vx, vy, yaw rate). gpr_state.goal_dev holds
+ * the object's goal [E][2]; pos / vel / acc are the mover's [E][2]. */
+typedef struct {
+    void *mover_rot_dev;
+    void *object_dev;
+} gpr_push_state;
+
+int gpr_push_configure(gpr_env *env, const gpr_push_params *params, const gpr_push_state *state);
+/* reset() / step() of BenchmarkPushingEnv; out.observation_dev is [E][4] (mover position, velocity) or [E][6] (+ acceleration,
+ * PU:556-559), achieved_goal / desired_goal are [E][2] (PU:564-568). */
+int gpr_push_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream);
+int gpr_push_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
+
 /* ---- stateless operators (f64, device pointers) --------------------------------------------------------------- */
 /* geometry_2D_utils.check_line_segments_intersect (GEO:9-69): p1,p2,q1,q2 [n][2]; out [n] bytes */
 int gpr_check_line_segments_intersect(int64_t n, const double *p1_dev, const double *p2_dev, const double *q1_dev,

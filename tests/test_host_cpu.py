@@ -47,6 +47,8 @@ def test_c_abi_struct_layout_matches_header():
     assert fields('gpr_config') == [f[0] for f in gpr._native.GprConfig._fields_]
     assert fields('gpr_state') == [f[0] for f in gpr._native.GprState._fields_]
     assert fields('gpr_step_out') == [f[0] for f in gpr._native.GprStepOut._fields_]
+    assert fields('gpr_push_params') == [f[0] for f in gpr._native.GprPushParams._fields_]
+    assert fields('gpr_push_state') == [f[0] for f in gpr._native.GprPushState._fields_]
 
 
 def test_invalid_configuration_is_reported_not_crashed():
@@ -235,3 +237,32 @@ def test_oracle_env_matches_reference_semantics(oracle):
         assert (moved <= 0.04 * 2.0 + 1e-9).all()  # 40 cycles x 1 ms x v_max
         seen_term |= bool(r['terminated'].any())
     assert seen_term and r['truncated'].all()
+
+
+def test_pushing_env_host_mirror_and_oracle_actuation(oracle):
+    """VecBenchmarkPushingEnv's constructor-time constants follow PU:232-288; the oracle's pushing step reproduces the reference's
+    closed-form actuator trajectories (its 24 parametrisations) when the object is out of reach."""
+    from conftest import load_npz
+    env = gpr.VecBenchmarkPushingEnv(num_envs=4, _host_only=True)
+    np.testing.assert_allclose(env.min_xy_pos, [0.11, 0.11]); np.testing.assert_allclose(env.max_xy_pos, [0.55, 0.55])
+    np.testing.assert_allclose(env.object_min_xy_pos, [0.22, 0.22]); np.testing.assert_allclose(env.object_max_xy_pos, [0.44, 0.44])
+    assert abs(env.min_mo_dist - np.hypot(0.1125, 0.1125)) < 1e-15 and env.obs_dim == 4
+    assert env.single_action_space.shape == (2,) and env.observation_space['achieved_goal'].shape == (4, 2)
+    assert gpr.VecBenchmarkPushingEnv(num_envs=1, learn_jerk=True, _host_only=True).obs_dim == 6
+    z = load_npz('trajectories.npz')
+    n = 0
+    for i in range(int(z['n'])):
+        if str(z[f'{i}_env']) != 'pushing':
+            continue
+        mode = str(z[f'{i}_mode'])
+        o = oracle.OraclePushingEnv(1, std_noise=0.0, num_cycles=int(z[f'{i}_num_cycles']), v_max=0.01, a_max=0.2, j_max=150.0,
+                                    learn_jerk=(mode == 'jerk'), max_episode_steps=None, autoreset='disabled')
+        o.reset(seed=0)
+        o.pos[0] = z[f'{i}_starts'].reshape(-1); o.object[0, :2] = [0.12, 0.36]
+        err = 0.0
+        for t in range(100):
+            o.step(z[f'{i}_deriv'][None, :])
+            err = max(err, np.abs(o.pos[0] - z[f'{i}_pos'][t]).max(), np.abs(o.vel[0] - z[f'{i}_vel'][t]).max())
+        assert err < 1e-12, (i, err)
+        n += 1
+    assert n == 24
