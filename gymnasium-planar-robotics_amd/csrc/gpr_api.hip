@@ -166,6 +166,9 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
     const double slack = sizeof(RT) == 8 ? 1e-12 : 1e-5;
     c.band_p = (RT)(g.std_noise[0] * NORMAL_MAX_RADIUS * 1.001 + slack);
     c.band_v = (RT)(g.std_noise[1] * NORMAL_MAX_RADIUS * 1.001 + slack);
+    // per-cycle displacement bound of one mover: after the clamp |v| <= v_max + band_v (PL:634-643), p moves by dt * v; slack
+    // for the rounding of p = p0 + dp (a few ulp of a coordinate) and of dt * v
+    c.step1 = (RT)(g.cycle_time * (g.v_max + (double)c.band_v) * 1.001 + (sizeof(RT) == 8 ? 1e-12 : 2e-6));
     c.gx0 = (RT)(e.xc.front() - g.tile_half_size[0]); c.gx1 = (RT)(e.xc.back() + g.tile_half_size[0]);
     c.gy0 = (RT)(e.yc.front() - g.tile_half_size[1]); c.gy1 = (RT)(e.yc.back() + g.tile_half_size[1]);
 }
@@ -318,7 +321,7 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     P.layout_full = full;
     // validation switch: GPR_EAGER_NOISE=1 draws every noise sample of every cycle instead of only those that can matter
     const char *eager = std::getenv("GPR_EAGER_NOISE");
-    P.eager_noise = eager && eager[0] == '1';
+    P.eager_noise = eager && eager[0] == '1';  // also runs both collision checks on every cycle (no skip ladder)
     fill_cst<float>(*e, P.cf);
     fill_cst<double>(*e, P.cd);
     *out_env = e;

@@ -29,6 +29,7 @@ template <typename RT> struct Cst {
     RT max_csum_step, max_csum_safe;  // max over mover pairs of (c_i + c_j), without / with the safety offset (BE:390,409)
     RT gx0, gx1, gy0, gy1;            // outer edges of the tile grid: lo of the first tile, hi of the last tile, per axis
     RT band_p, band_v;                // how far a noisy position / velocity reading can be from the true one (+ rounding slack)
+    RT step1;                         // upper bound of |p(cycle k+1) - p(cycle k)| of one mover: dt (v_max + band_v), with rounding slack
 };
 
 // Everything a kernel needs, passed by value (kernarg segment).
@@ -196,6 +197,32 @@ template <int LPE, int D> __device__ __forceinline__ double rot(double v) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// (rot(x) - x, rot(y) - y) with the lane permute folded into the subtract: one v_sub_f32_dpp per component instead of
+// v_mov_b32_dpp + v_sub (the compiler pairs the two subtracts into a v_pk_add_f32, which cannot carry a DPP modifier, and
+// then needs the moves). s_nop 1: a DPP read needs two wait states after the VALU write of its source.
+#define GPR_ROT_DIFF2(CTRL)                                                                                              \
+    asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+        "v_sub_f32_dpp %1, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                      \
+        : "=&v"(dx), "=&v"(dy) : "v"(x), "v"(y))
+template <int LPE, int D> __device__ __forceinline__ void rot_diff2(float x, float y, float &dx, float &dy) {
+    if constexpr (LPE == 2) { GPR_ROT_DIFF2("quad_perm:[1,0,3,2]"); }
+    else if constexpr (LPE == 4 && D == 1) { GPR_ROT_DIFF2("quad_perm:[1,2,3,0]"); }
+    else if constexpr (LPE == 4 && D == 2) { GPR_ROT_DIFF2("quad_perm:[2,3,0,1]"); }
+    else if constexpr (LPE == 16 && D == 1) { GPR_ROT_DIFF2("row_ror:15"); }
+    else if constexpr (LPE == 16 && D == 2) { GPR_ROT_DIFF2("row_ror:14"); }
+    else if constexpr (LPE == 16 && D == 3) { GPR_ROT_DIFF2("row_ror:13"); }
+    else if constexpr (LPE == 16 && D == 4) { GPR_ROT_DIFF2("row_ror:12"); }
+    else if constexpr (LPE == 16 && D == 5) { GPR_ROT_DIFF2("row_ror:11"); }
+    else if constexpr (LPE == 16 && D == 6) { GPR_ROT_DIFF2("row_ror:10"); }
+    else if constexpr (LPE == 16 && D == 7) { GPR_ROT_DIFF2("row_ror:9"); }
+    else if constexpr (LPE == 16 && D == 8) { GPR_ROT_DIFF2("row_ror:8"); }
+    else { dx = rot<LPE, D>(x) - x; dy = rot<LPE, D>(y) - y; }
+}
+#undef GPR_ROT_DIFF2
+template <int LPE, int D> __device__ __forceinline__ void rot_diff2(double x, double y, double &dx, double &dy) {
+    dx = rot<LPE, D>(x) - x; dy = rot<LPE, D>(y) - y;
+}
+
 // bits of the predicate for the LPE lanes of this lane's env group (bit m = mover m)
 template <int LPE> __device__ __forceinline__ uint32_t group_bits(bool pred) {
     unsigned long long b = __ballot(pred);
@@ -282,6 +309,14 @@ template <typename RT> __device__ __forceinline__ CircleSize<RT> circle_size(con
     return CircleSize<RT>{c, c * C.inv_wx, c * C.inv_wy, (RT)0.5 * (C.gx1 - C.gx0) - c, (RT)0.5 * (C.gy1 - C.gy0) - c};
 }
 
+// Full grid (every cell holds a tile, circle smaller than half a tile): how far the circle's centre reaches from the grid
+// centre, as ONE number comparable with cs.wx: max(|x - cx|, |y - cy| + (wx - wy)). The position is valid iff it is < cs.wx
+// (both axis margins positive). Three vector instructions after the centre subtraction.
+template <typename RT> __device__ __forceinline__ RT wall_reach_full(const Cst<RT> &C, RT x, RT y, const CircleSize<RT> &cs) {
+    const RT dx = x - (RT)0.5 * (C.gx0 + C.gx1), dy = y - (RT)0.5 * (C.gy0 + C.gy1);
+    return __builtin_fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy) + (cs.wx - cs.wy));
+}
+
 // generic (any number of tiles under the centre, incl. none) form of BE:518-540 + BE:785, table edges compared literally
 template <typename RT> __device__ __forceinline__ bool pos_valid_circle_slow(const Tables<RT> &T, int Tx, int Ty, int ix, int iy, RT x, RT y, RT c) {
     bool any = false, all = true, valid3 = false;
@@ -334,9 +369,9 @@ __device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KPar
             // Every cell of the grid holds a tile and the circle is smaller than half a tile: an edge between two tiles
             // never invalidates (BE:582-648 find the neighbour), so BE:459-788 reduces to "the circle's bounding box lies
             // strictly inside the grid": the smaller of the two axis margins is positive. No table.
-            const RT m = __builtin_fminf(cs.wx - __builtin_fabsf(x - (RT)0.5 * (C.gx0 + C.gx1)), cs.wy - __builtin_fabsf(y - (RT)0.5 * (C.gy0 + C.gy1)));
-            if constexpr (UNC) *uncertain = !(__builtin_fabsf(m) > band);
-            return m > (RT)0;
+            const RT e = wall_reach_full<RT>(C, x, y, cs);
+            if constexpr (UNC) *uncertain = !(__builtin_fabsf(cs.wx - e) > band);
+            return e < cs.wx;
         }
         // General layouts, in tile coordinates: fx = x / tile_width; its integer part names the tile, its fraction is the
         // position inside it, and the four "safe" compares of BE:545-558 become frac > c/w and frac < 1 - c/w. One LDS read
@@ -574,14 +609,21 @@ __device__ __forceinline__ bool box_pair_hit(const Pose<RT> &q, RT c0, RT c1, RT
 template <typename RT, int LPE, int D> struct PairSweep {
     // smallest of the pair distances at rotation D .. LPE/2
     static __device__ __forceinline__ RT run(RT x, RT y) {
-        const RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
-        const RT d2 = dx * dx + dy * dy;
-        const RT m = Math<RT>::literal ? Math<RT>::sqrt_(d2) : d2;
-        if constexpr (D < LPE / 2) {
-            const RT rest = PairSweep<RT, LPE, D + 1>::run(x, y);
-            return rest < m ? rest : m;
+        if constexpr (Math<RT>::literal) {
+            const RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
+            const RT m = Math<RT>::sqrt_(dx * dx + dy * dy);
+            if constexpr (D < LPE / 2) {
+                const RT rest = PairSweep<RT, LPE, D + 1>::run(x, y);
+                return rest < m ? rest : m;
+            } else {
+                return m;
+            }
         } else {
-            return m;
+            RT dx, dy;
+            rot_diff2<LPE, D>(x, y, dx, dy);
+            const RT m = __builtin_fmaf(dx, dx, dy * dy);
+            if constexpr (D < LPE / 2) return __builtin_fminf(PairSweep<RT, LPE, D + 1>::run(x, y), m);
+            else return m;
         }
     }
 };

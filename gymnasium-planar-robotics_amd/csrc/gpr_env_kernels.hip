@@ -227,6 +227,133 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const RT pair_thr = Math<RT>::literal ? C.max_csum_step : C.max_csum_step * C.max_csum_step;
     const RT pair_band = Math<RT>::literal ? band_pair : (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
 
+    if constexpr (!Math<RT>::literal && SHAPE == 0) {
+    // ---------------------------------------------------------------------------------------------------------------
+    // Throughput loop: float arithmetic, circle shape, acceleration actions. Same decisions as the generic loop below.
+    //
+    // Measured on MI355X (scratch/ubench): a SIMD retires a wave64 vector instruction every ~4.5 clocks in dependent code
+    // (2.7 with independent neighbours, ~10 for rsq/log/sin), and a wave-level decision that hangs on a vector compare
+    // (v_cmp -> VCC -> s_cbranch) costs its wavefront 40-60 clocks of latency. With the four wavefronts per SIMD this
+    // workload provides, the loop is vector-issue bound as long as it takes few such decisions per cycle. So:
+    //  * the common cycle is straight-line: v += dt a; p += dt v (4 packed instructions), the wall reach (4) and the smallest
+    //    pair distance (9) of the new position, and ONE combined test "is any lane within the noise band of a wall or of
+    //    another mover?" (2 compares, 1 branch). Only if it fires are the exact, noisy checks (and the freeze) evaluated;
+    //  * the speed clamp (PL:634-643) is not even looked at while it provably cannot fire: the acceleration is constant
+    //    during an env-step, so |v + dt a| grows by at most |dt a| per cycle, and a lane that is k |dt a| below v_max - band_v
+    //    stays unclamped for k cycles. The wave-wide k (rungs 3, 10, 40) sets the next cycle at which speeds are looked at;
+    //    a wavefront with a lane at the speed limit (14 % of them) runs the clamp every cycle, in line.
+    // All shortcuts are exact: results are bit-identical to evaluating everything on every cycle, which GPR_EAGER_NOISE=1
+    // does (the thresholds are then set so that every shortcut test fails) and the tests compare. Lanes that must not vote
+    // (dead / padding lanes, frozen envs) are taken out through per-lane thresholds instead of scalar mask arithmetic.
+    // ---------------------------------------------------------------------------------------------------------------
+    constexpr int KC1 = 3, KC2 = 10, KC3 = 40;
+    const bool every = P.eager_noise != 0;
+    const RT INF = Math<RT>::inf();
+    RT wx_l = cw_step.wx;                                  // wall: valid iff reach < wx_l (full grid)
+    RT w0 = every ? -INF : wx_l - C.band_p;                 // certainly valid, whatever the noise, iff reach < w0
+    const RT wband = every ? INF : C.band_p;
+    const RT pb = C.max_csum_step + band_pair;
+    RT pthr_l = pair_thr;                                  // pair: hit iff d2 <= pthr_l
+    RT p0r = every ? INF : pb * pb * (RT)1.00001;          // certainly no hit, whatever the noise, iff d2 > p0r
+    const RT pband = every ? INF : pair_band;
+    // Per-lane integration operands. A frozen env (BE:1904 break, or an env that only resets in this call) keeps its state:
+    // its lanes integrate with a zero time step, a zero increment and an unreachable clamp, and compare against wall limits of
+    // +inf and pair limits of -1 (never reached).
+    R2<RT> dtl{C.dt * a.x, C.dt * a.y};
+    RT dt_l = C.dt, vmax2_l = C.v_max * C.v_max;
+    const RT vlim_c = NOISE ? vlim : C.v_max;             // below this speed the clamp cannot fire (vlim = v_max - band_v)
+    RT vneed2_l = every ? (RT)-1 : (vlim_c > (RT)0 ? vlim_c * vlim_c : (RT)-1);
+    // clamp rungs: the squared speed below which the lane stays unclamped for KCi more cycles
+    const RT adt = Math<RT>::sqrt_(dtl.x * dtl.x + dtl.y * dtl.y) * (RT)1.00001 + (RT)1e-7;
+    auto rung = [&](int k) { const RT m = vlim_c * (RT)0.99999 - (RT)k * adt; return m > (RT)0 ? m * m : (RT)-1; };
+    RT c1r = rung(KC1), c2r = rung(KC2), c3r = rung(KC3);
+#define GPR_LANE_OUT() do { wx_l = w0 = INF; pthr_l = p0r = (RT)-1; c1r = c2r = c3r = INF; if (!every) vneed2_l = INF; } while (0)
+    if (!live) GPR_LANE_OUT();
+    if (lane_of(frozen_m)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
+    int next_c = 0;  // wave-uniform: the first cycle at which the speed clamp has to be looked at again
+    for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
+        // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
+        R2<RT> dvn{dv.x + dtl.x, dv.y + dtl.y};
+        if (cyc >= next_c) {
+            R2<RT> t{v.x + dtl.x, v.y + dtl.y};
+            RT n2 = t.x * t.x + t.y * t.y;
+            if (__ballot(!(n2 < vneed2_l)) == 0ull) {
+                const int k = __ballot(!(n2 < c1r)) != 0ull ? 0 : __ballot(!(n2 < c2r)) != 0ull ? KC1 : __ballot(!(n2 < c3r)) != 0ull ? KC2 : KC3;
+                next_c = cyc + 1 + k;
+            } else {
+                R2<RT> nv{(RT)0, (RT)0};
+                if constexpr (NOISE) {
+                    const R2<RT> n = rng_normal_pair<RT>(key, S * (uint32_t)cyc);  // PL:430
+                    nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
+                    t.x += nv.x; t.y += nv.y;
+                    n2 = t.x * t.x + t.y * t.y;
+                }
+                const bool cl = n2 >= vmax2_l;  // PL:634, inclusive
+                const RT sc = C.v_max * Math<RT>::rsqrt_(n2);
+                dvn.x = cl ? (t.x * sc - nv.x) - v0.x : dvn.x;
+                dvn.y = cl ? (t.y * sc - nv.y) - v0.y : dvn.y;
+            }
+        }
+        dv = dvn;
+        v.x = v0.x + dv.x; v.y = v0.y + dv.y;
+        dp.x += dt_l * v.x; dp.y += dt_l * v.y;  // semi-implicit Euler: the position moves with the NEW velocity
+        p.x = p0.x + dp.x; p.y = p0.y + dp.y;
+        // BE:1888-1901, noise-free and with the noise bands added: can anything at all have happened?
+        RT e = (RT)0, md = INF;
+        unsigned long long sp_w, sp_p = 0ull;
+        bool w_valid = true, w_unc = false;
+        if constexpr (FULL) {
+            e = wall_reach_full<RT>(C, p.x, p.y, cw_step);
+            sp_w = __ballot(!(e < w0));
+        } else {
+            w_valid = pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &w_unc);
+            sp_w = every ? ~0ull : (__ballot(!w_valid | w_unc) & live_m & ~frozen_m);
+        }
+        if constexpr (LPE > 1) {
+            md = pair_min_dist<RT, LPE>(p.x, p.y);
+            sp_p = __ballot(md <= p0r);
+        }
+        if ((sp_w | sp_p) == 0ull) continue;
+        // ---- something is close: the exact checks, each on its own noisy position read ----
+        unsigned long long wraw, hraw = 0ull;
+        if constexpr (FULL) {
+            wraw = __ballot(!(e < wx_l));
+            if constexpr (NOISE) {
+                if (__ballot(!(__builtin_fabsf(wx_l - e) > wband)) != 0ull) {
+                    const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                    wraw = __ballot(!(wall_reach_full<RT>(C, pw.x, pw.y, cw_step) < wx_l));
+                }
+            }
+        } else {
+            wraw = __ballot(!w_valid);
+            if constexpr (NOISE) {
+                if (every | ((__ballot(w_unc) & live_m & ~frozen_m) != 0ull)) {
+                    const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                    wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step));
+                }
+            }
+            wraw &= live_m & ~frozen_m;
+        }
+        if constexpr (LPE > 1) {
+            hraw = __ballot(md <= pthr_l);  // BE:409, inclusive
+            if constexpr (NOISE) {
+                if (__ballot(absr(md - pthr_l) <= pband) != 0ull) {
+                    const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
+                    hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
+                }
+            }
+        }
+        // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle
+        if ((wraw | hraw) != 0ull) {
+            wc_m |= wraw;
+            mc_m |= hraw;
+            const unsigned long long nf = group_or<LPE>(wraw | hraw);
+            frozen_m |= nf;
+            if (lane_of(nf)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
+        }
+    }
+#undef GPR_LANE_OUT
+    } else {
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882)
         if constexpr (Math<RT>::literal) {
@@ -333,6 +460,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         wc_m |= wb;
         mc_m |= mb;
         frozen_m |= group_or<LPE>(wb | mb);
+    }
     }
     wc_m = group_or<LPE>(wc_m);
     mc_m = group_or<LPE>(mc_m);
