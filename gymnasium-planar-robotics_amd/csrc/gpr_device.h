@@ -312,9 +312,11 @@ template <typename RT> __device__ __forceinline__ CircleSize<RT> circle_size(con
 // Full grid (every cell holds a tile, circle smaller than half a tile): how far the circle's centre reaches from the grid
 // centre, as ONE number comparable with cs.wx: max(|x - cx|, |y - cy| + (wx - wy)). The position is valid iff it is < cs.wx
 // (both axis margins positive). Three vector instructions after the centre subtraction.
+template <typename RT> __device__ __forceinline__ RT wall_reach_centred(RT qx, RT qy, const CircleSize<RT> &cs) {  // q = p - grid centre
+    return __builtin_fmaxf(__builtin_fabsf(qx), __builtin_fabsf(qy) + (cs.wx - cs.wy));
+}
 template <typename RT> __device__ __forceinline__ RT wall_reach_full(const Cst<RT> &C, RT x, RT y, const CircleSize<RT> &cs) {
-    const RT dx = x - (RT)0.5 * (C.gx0 + C.gx1), dy = y - (RT)0.5 * (C.gy0 + C.gy1);
-    return __builtin_fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy) + (cs.wx - cs.wy));
+    return wall_reach_centred<RT>(x - (RT)0.5 * (C.gx0 + C.gx1), y - (RT)0.5 * (C.gy0 + C.gy1), cs);
 }
 
 // generic (any number of tiles under the centre, incl. none) form of BE:518-540 + BE:785, table edges compared literally
@@ -618,12 +620,23 @@ template <typename RT, int LPE, int D> struct PairSweep {
             } else {
                 return m;
             }
-        } else {
+        } else if constexpr (LPE == 2) {
             RT dx, dy;
             rot_diff2<LPE, D>(x, y, dx, dy);
-            const RT m = __builtin_fmaf(dx, dx, dy * dy);
-            if constexpr (D < LPE / 2) return __builtin_fminf(PairSweep<RT, LPE, D + 1>::run(x, y), m);
-            else return m;
+            return __builtin_fmaf(dx, dx, dy * dy);
+        } else {
+            // two rotations at a time: the four differences come out of DPP subtracts, the two squared distances out of one
+            // packed multiply + one packed fma
+            static_assert(D % 2 == 1 && D + 1 <= LPE / 2, "rotations are taken in pairs");
+            typedef RT V2 __attribute__((ext_vector_type(2)));
+            RT dx0, dy0, dx1, dy1;
+            rot_diff2<LPE, D>(x, y, dx0, dy0);
+            rot_diff2<LPE, D + 1>(x, y, dx1, dy1);
+            const V2 dx{dx0, dx1}, dy{dy0, dy1};
+            const V2 m = __builtin_elementwise_fma(dx, dx, dy * dy);
+            const RT mm = __builtin_fminf(m.x, m.y);
+            if constexpr (D + 1 < LPE / 2) return __builtin_fminf(PairSweep<RT, LPE, D + 2>::run(x, y), mm);
+            else return mm;
         }
     }
 };

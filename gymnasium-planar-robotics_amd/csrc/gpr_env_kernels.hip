@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     if (!live) GPR_LANE_OUT();
     if (lane_of(frozen_m)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
     int next_c = 0;  // wave-uniform: the first cycle at which the speed clamp has to be looked at again
+    const R2<RT> q0{p0.x - (RT)0.5 * (C.gx0 + C.gx1), p0.y - (RT)0.5 * (C.gy0 + C.gy1)};
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
         R2<RT> dvn{dv.x + dtl.x, dv.y + dtl.y};
@@ -297,23 +298,27 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         dv = dvn;
         v.x = v0.x + dv.x; v.y = v0.y + dv.y;
         dp.x += dt_l * v.x; dp.y += dt_l * v.y;  // semi-implicit Euler: the position moves with the NEW velocity
-        p.x = p0.x + dp.x; p.y = p0.y + dp.y;
+        // the checks work on q = p - grid centre = q0 + dp (pair distances do not care, the wall reach wants it anyway);
+        // p itself is only needed by the table-driven wall check of general layouts, by noisy reads, and after the loop
+        const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
         // BE:1888-1901, noise-free and with the noise bands added: can anything at all have happened?
         RT e = (RT)0, md = INF;
         unsigned long long sp_w, sp_p = 0ull;
         bool w_valid = true, w_unc = false;
         if constexpr (FULL) {
-            e = wall_reach_full<RT>(C, p.x, p.y, cw_step);
+            e = wall_reach_centred<RT>(q.x, q.y, cw_step);
             sp_w = __ballot(!(e < w0));
         } else {
+            p.x = p0.x + dp.x; p.y = p0.y + dp.y;
             w_valid = pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &w_unc);
             sp_w = every ? ~0ull : (__ballot(!w_valid | w_unc) & live_m & ~frozen_m);
         }
         if constexpr (LPE > 1) {
-            md = pair_min_dist<RT, LPE>(p.x, p.y);
+            md = pair_min_dist<RT, LPE>(q.x, q.y);
             sp_p = __ballot(md <= p0r);
         }
         if ((sp_w | sp_p) == 0ull) continue;
+        p.x = p0.x + dp.x; p.y = p0.y + dp.y;
         // ---- something is close: the exact checks, each on its own noisy position read ----
         unsigned long long wraw, hraw = 0ull;
         if constexpr (FULL) {
@@ -352,6 +357,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             if (lane_of(nf)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
         }
     }
+    p.x = p0.x + dp.x; p.y = p0.y + dp.y;
 #undef GPR_LANE_OUT
     } else {
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
