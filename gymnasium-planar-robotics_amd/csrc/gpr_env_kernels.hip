@@ -171,6 +171,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
     const int64_t env_global = P.env_id_offset + envc;
 
+    __shared__ int reset_count, reset_list[BLOCK];  // envs of this block that need a reset (local env index * 2 + "reset only")
+    if (threadIdx.x == 0) reset_count = 0;
+    const int64_t env_block_base = (int64_t)blockIdx.x * (BLOCK / LPE);
+
     // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
     R2<RT> a = load2<ST, RT>(P.action, idx);
     R2<RT> p = load2<ST, RT>(P.pos, idx);
@@ -184,6 +188,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
     if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
+    else __syncthreads();  // (reset_count is initialised)
     const Tables<RT> T = make_tables<RT>(lds, P);
     const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);  // BE:487, add_safety_offset=False
 
@@ -480,39 +485,56 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 
     Obs<RT> o = observe<ST, RT, LPE, NOISE>(P, key, S * (uint32_t)P.num_cycles, p, v, g, mc, wc, live);
     int el_new = reset_first ? el : el + 1;
-    bool trunc = (P.max_episode_steps > 0) & (el_new >= P.max_episode_steps);  // gymnasium TimeLimit
+    const bool trunc = (P.max_episode_steps > 0) & (el_new >= P.max_episode_steps);  // gymnasium TimeLimit
     const bool done = (o.terminated | trunc) & !reset_first;
     const bool need = live_env & (reset_first | ((P.autoreset == 1) & done));
-    bool succ = o.is_success;
-
-    if (__ballot(need) != 0ull) {
-        if ((P.autoreset == 1) & need & live) {  // same-step: the terminal observation goes to final_*
-            if (P.final_obs) store_obs<ST, RT, JERK>(P, P.final_obs, P.final_ag, P.final_dg, envc, mv, idx, o.vel, acc, o.ag, g, true);
-        }
-        R2<RT> rp = p, rg = g;
-        bool rwc, rmc;
-        Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, rp, rg, rwc, rmc);
-        if (need) {
-            p = rp; g = rg;
-            v = R2<RT>{(RT)0, (RT)0};
-            acc = R2<RT>{(RT)0, (RT)0};
-            el_new = 0;
-            o.vel = ro.vel; o.ag = ro.ag;
-            if (reset_first) {  // the reset IS this call's result
-                o.reward = (RT)0; o.terminated = false; trunc = false;
-                wc = rwc; mc = rmc; succ = ro.is_success;
-            }
-        }
-    }
     if ((P.autoreset == 2) & done) el_new = -1;
+    if (need) el_new = 0;
 
+    // What the stepping wavefront stores: everything of the envs that go on, and of an env that ended in this call its
+    // terminal observation (same-step mode: final_*) and the step's scalars. The reset itself -- new state, goal and
+    // observation; for an env that only resets in this call (next-step mode) also the scalars -- is left to the reset pass.
     if (live) {
-        store2<ST, RT>(P.pos, idx, p);
-        store2<ST, RT>(P.vel, idx, v);
-        if constexpr (JERK) store2<ST, RT>(P.acc, idx, acc);
-        if (need) store2<ST, RT>(P.goal, idx, g);
-        store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, envc, mv, idx, o.vel, acc, o.ag, g, P.dg != P.goal);
-        if (mv == 0) store_env_scalars<ST, RT>(P, envc, el_new, o.reward, o.terminated, trunc, succ, mc, wc);
+        if (!need) {
+            store2<ST, RT>(P.pos, idx, p);
+            store2<ST, RT>(P.vel, idx, v);
+            if constexpr (JERK) store2<ST, RT>(P.acc, idx, acc);
+            store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, envc, mv, idx, o.vel, acc, o.ag, g, P.dg != P.goal);
+        } else if ((P.autoreset == 1) & (P.final_obs != nullptr)) {
+            store_obs<ST, RT, JERK>(P, P.final_obs, P.final_ag, P.final_dg, envc, mv, idx, o.vel, acc, o.ag, g, true);
+        }
+        if ((mv == 0) & !reset_first) store_env_scalars<ST, RT>(P, envc, el_new, o.reward, o.terminated, trunc, o.is_success, mc, wc);
+        if (need & (mv == 0)) reset_list[atomicAdd(&reset_count, 1)] = (int)(envc - env_block_base) * 2 + (int)reset_first;
+    }
+
+    // RESET PASS. A reset is a pure function of (seed, tick, env id), so the envs that need one are handed over as a list of
+    // env ids and packed densely into as few wavefronts of the block as they fill (64 / LPE envs each): with ~14 % of the envs
+    // ending per step, one wavefront resets what would otherwise keep all four busy with rejection sampling for one or two
+    // envs each.
+    __syncthreads();
+    const int n_reset = reset_count;
+    constexpr int EPW = 64 / LPE;  // envs per wavefront
+    for (int base = (int)(threadIdx.x >> 6) * EPW; base < n_reset; base += (BLOCK / 64) * EPW) {
+        const int slot = base + (int)(threadIdx.x & 63) / LPE;
+        const bool have = slot < n_reset;
+        const int entry = reset_list[have ? slot : base];
+        const int64_t renv = env_block_base + (entry >> 1);
+        const bool rfirst = (entry & 1) != 0;
+        const bool rlive = have & (mv < M);
+        R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+        bool rwc, rmc;
+        const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, rp, rg, rwc, rmc);
+        if (rlive) {
+            const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
+            const R2<RT> zero{(RT)0, (RT)0};
+            store2<ST, RT>(P.pos, ridx, rp);
+            store2<ST, RT>(P.vel, ridx, zero);
+            if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
+            store2<ST, RT>(P.goal, ridx, rg);
+            store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
+            // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
+            if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
+        }
     }
 }
 
