@@ -170,7 +170,7 @@ def main():
                 'sigma0_env_steps_per_s': world * E * K / wall0, 'sigma0_kernel_us': gpu_ms0 * 1e3 / K,
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true>', 'kernel_us': kernel_s * 1e6,
+                         'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>', 'kernel_us': kernel_s * 1e6,
                          'algorithmic_bytes_per_env_step': B},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -275,6 +275,9 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 #define GPR_LANE_OUT() do { wx_l = w0 = INF; pthr_l = p0r = (RT)-1; c1r = c2r = c3r = INF; if (!every) vneed2_l = INF; } while (0)
     if (!live) GPR_LANE_OUT();
     if (lane_of(frozen_m)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
+    // index of a noise draw of this cycle, formed in scalar registers where it is needed (kept out of the loop's induction
+    // variables: the common cycle draws nothing)
+    auto draw_index = [&](int cycle, uint32_t which) { uint32_t q = S * (uint32_t)cycle + which; asm volatile("" : "+s"(q)); return q; };
     int next_c = 0;  // wave-uniform: the first cycle at which the speed clamp has to be looked at again
     const R2<RT> q0{p0.x - (RT)0.5 * (C.gx0 + C.gx1), p0.y - (RT)0.5 * (C.gy0 + C.gy1)};
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             } else {
                 R2<RT> nv{(RT)0, (RT)0};
                 if constexpr (NOISE) {
-                    const R2<RT> n = rng_normal_pair<RT>(key, S * (uint32_t)cyc);  // PL:430
+                    const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));  // PL:430
                     nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
                     t.x += nv.x; t.y += nv.y;
                     n2 = t.x * t.x + t.y * t.y;
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             wraw = __ballot(!(e < wx_l));
             if constexpr (NOISE) {
                 if (__ballot(!(__builtin_fabsf(wx_l - e) > wband)) != 0ull) {
-                    const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                    const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u));
                     wraw = __ballot(!(wall_reach_full<RT>(C, pw.x, pw.y, cw_step) < wx_l));
                 }
             }
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             wraw = __ballot(!w_valid);
             if constexpr (NOISE) {
                 if (every | ((__ballot(w_unc) & live_m & ~frozen_m) != 0ull)) {
-                    const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                    const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u));
                     wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step));
                 }
             }
@@ -348,7 +351,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             hraw = __ballot(md <= pthr_l);  // BE:409, inclusive
             if constexpr (NOISE) {
                 if (__ballot(absr(md - pthr_l) <= pband) != 0ull) {
-                    const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
+                    const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u + R));
                     hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
                 }
             }
