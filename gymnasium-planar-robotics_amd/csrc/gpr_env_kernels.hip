@@ -127,6 +127,72 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     return observe<ST, RT, LPE, NOISE>(P, kn, 2u * R, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
 }
 
+// The same reset for ONE env per wavefront, for wide env groups (LPE >= 8): the 64 / LPE lane groups evaluate 64 / LPE
+// consecutive rejection trials at once and the first valid one in trial order wins -- exactly the candidate the sequential
+// loop of group_reset accepts (the draws are indexed by trial), in 64 / LPE times fewer rounds. The reference samples all movers
+// at once and rejects the whole set on any conflict (PL:369-385): with 16 movers that is ~45 trials per reset.
+// Wave-cooperative and wave-uniform: every lane works on env `env_global`; all lane groups return the same p, g, flags.
+template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE>
+__device__ __forceinline__ Obs<RT> group_reset_wide(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, RT c, RT c1,
+                                                    R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
+    static_assert(LPE >= 8 && SHAPE == 0, "wide reset: circle shape, 8 or 16 lanes per env");
+    const Cst<RT> &C = cst<RT>(P);
+    const int M = P.M;
+    constexpr int G = 64 / LPE;
+    const int gi = (int)(__lane_id() / LPE);
+    const bool live = mv < M;
+    const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);
+    const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, (uint32_t)mvc);
+    const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
+    const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, (uint32_t)mvc);
+    const RT sx = C.max_x - C.min_x, sy = C.max_y - C.min_y;
+    auto candidate = [&](uint32_t key, int trial) {
+        R2<RT> cn;
+        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(key, 2u * (uint32_t)trial));
+        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(key, 2u * (uint32_t)trial + 1u));
+        if (mv >= M) cn.x = cn.y = far_away<RT>();
+        return cn;
+    };
+    auto from_group = [&](RT v, int grp) {  // the value lane (grp, mv) holds
+        if constexpr (sizeof(RT) == 4) {
+            return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((grp * LPE + mv) << 2, (int)__float_as_uint(v)));
+        } else {
+            const uint64_t b = (uint64_t)__double_as_longlong(v);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((grp * LPE + mv) << 2, (int)(uint32_t)b);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((grp * LPE + mv) << 2, (int)(uint32_t)(b >> 32));
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        }
+    };
+    for (int pass = 0; pass < 2; ++pass) {  // 0: start positions (PL:369-385), 1: goals (PL:395-413)
+        const uint32_t key = pass == 0 ? ks : kg;
+        bool found = false;
+        R2<RT> win{(RT)0, (RT)0};
+        for (int base = 0; base < P.max_reset_trials; base += G) {
+            const int trial = base + gi;
+            const R2<RT> cn = candidate(key, trial);
+            const bool w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);  // PL:379 / PL:403-404
+            const RT md = pair_min_dist<RT, LPE>(cn.x, cn.y);
+            const bool hit = live & (pass == 0 ? dist_le<RT>(md, C.max_csum_safe) : dist_lt<RT>(md, C.min_goal_dist));  // PL:381-383 / PL:407-413
+            const bool ok = !group_any<LPE>(w | hit) & (trial < P.max_reset_trials);
+            const unsigned long long okm = __ballot(ok);
+            if (okm != 0ull) {
+                const int grp = __builtin_ctzll(okm) / LPE;  // the first valid trial in trial order
+                win.x = from_group(cn.x, grp); win.y = from_group(cn.y, grp);
+                found = true;
+                break;
+            }
+        }
+        if (!found) win = candidate(key, P.max_reset_trials - 1);  // trials exhausted: the last candidate stands (as in group_reset)
+        if (pass == 0) p = win; else g = win;
+    }
+    // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
+    const R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
+    wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
+    const R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, 1u);
+    mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+    return observe<ST, RT, LPE, NOISE>(P, kn, 2u, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
+}
+
 template <typename ST, typename RT>
 __device__ __forceinline__ void store_env_scalars(const KParams &P, int64_t env, int el, RT reward, bool term, bool trunc, bool succ, bool mc,
                                                   bool wc) {
@@ -517,6 +583,28 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     __syncthreads();
     const int n_reset = reset_count;
     constexpr int EPW = 64 / LPE;  // envs per wavefront
+    if constexpr (LPE >= 8 && SHAPE == 0) {
+        // wide env groups: one env per wavefront at a time, its 64 / LPE lane groups try 64 / LPE rejection trials in parallel
+        for (int i = (int)(threadIdx.x >> 6); i < n_reset; i += BLOCK / 64) {
+            const int entry = reset_list[i];
+            const int64_t renv = env_block_base + (entry >> 1);
+            const bool rfirst = (entry & 1) != 0;
+            R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+            bool rwc, rmc;
+            const Obs<RT> ro = group_reset_wide<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, c, c1, rp, rg, rwc, rmc);
+            if (((threadIdx.x & 63) < LPE) & (mv < M)) {
+                const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
+                const R2<RT> zero{(RT)0, (RT)0};
+                store2<ST, RT>(P.pos, ridx, rp);
+                store2<ST, RT>(P.vel, ridx, zero);
+                if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
+                store2<ST, RT>(P.goal, ridx, rg);
+                store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
+                if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
+            }
+        }
+        return;
+    }
     for (int base = (int)(threadIdx.x >> 6) * EPW; base < n_reset; base += (BLOCK / 64) * EPW) {
         const int slot = base + (int)(threadIdx.x & 63) / LPE;
         const bool have = slot < n_reset;
