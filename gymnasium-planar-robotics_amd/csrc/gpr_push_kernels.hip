@@ -125,19 +125,58 @@ __device__ __forceinline__ PushObs<RT> push_observe(const KParams &P, const Push
     return o;
 }
 
+// the value lane L of the wavefront holds (L wave-uniform)
+template <typename RT> __device__ __forceinline__ RT lane_bcast(RT v, int L);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int L) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), L));
+}
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int L) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, L), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), L);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 template <typename ST, typename RT, bool NOISE, bool FULL>
 __device__ __forceinline__ PushObs<RT> push_reset_one(const KParams &P, const PushCst<RT> &Q, const Tables<RT> &T, int64_t env_global, RT c,
-                                                      R2<RT> &p, R2<RT> &g, RT &ox, RT &oy, bool &wc) {
+                                                      bool need, R2<RT> &p, R2<RT> &g, RT &ox, RT &oy, bool &wc) {
     const Cst<RT> &C = cst<RT>(P);
     const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, 0u), kg = rng_key(P, KIND_RESET_GOAL, env_global, 0u);
     const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, 0u);
     p.x = stored<ST, RT>(C.min_x + (C.max_x - C.min_x) * rng_uniform<RT>(ks, 0u));  // PU:389-391
     p.y = stored<ST, RT>(C.min_y + (C.max_y - C.min_y) * rng_uniform<RT>(ks, 1u));
-    for (int trial = 0; trial < P.max_reset_trials; ++trial) {  // PU:396-407
-        ox = stored<ST, RT>(Q.omin_x + (Q.omax_x - Q.omin_x) * rng_uniform<RT>(ks, 2u + 2u * (uint32_t)trial));
-        oy = stored<ST, RT>(Q.omin_y + (Q.omax_y - Q.omin_y) * rng_uniform<RT>(ks, 3u + 2u * (uint32_t)trial));
-        const RT dx = ox - p.x, dy = oy - p.y;
-        if (Math<RT>::sqrt_(dx * dx + dy * dy) > Q.min_mo_dist) break;  // PU:407, strict
+    // PU:396-407: object start by rejection, strict distance rule. Where the mover starts near the centre of the 3x3 tiles
+    // almost no object position qualifies (the reference then loops for thousands of trials, at the very centre forever), so
+    // the search is wave-cooperative: every lane tries its own first 8 trials; the lanes still looking are then served one
+    // at a time, all 64 lanes testing 64 consecutive trials of that env, the first valid one in trial order wins -- the same
+    // candidate the sequential loop accepts (the draws are indexed by trial). After max_reset_trials the last candidate stands.
+    auto candidate = [&](uint32_t key, int trial, RT &cx, RT &cy) {
+        cx = stored<ST, RT>(Q.omin_x + (Q.omax_x - Q.omin_x) * rng_uniform<RT>(key, 2u + 2u * (uint32_t)trial));
+        cy = stored<ST, RT>(Q.omin_y + (Q.omax_y - Q.omin_y) * rng_uniform<RT>(key, 3u + 2u * (uint32_t)trial));
+    };
+    auto far_enough = [&](RT cx, RT cy, RT mx, RT my) { const RT dx = cx - mx, dy = cy - my; return Math<RT>::sqrt_(dx * dx + dy * dy) > Q.min_mo_dist; };
+    constexpr int NSELF = 8;
+    bool pending = need;
+    for (int trial = 0; trial < NSELF && trial < P.max_reset_trials; ++trial) {
+        if (__ballot(pending) == 0ull) break;
+        RT cx, cy;
+        candidate(ks, trial, cx, cy);
+        if (pending) { ox = cx; oy = cy; pending = !far_enough(cx, cy, p.x, p.y); }
+    }
+    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm &= pm - 1ull) {
+        const int L = __builtin_ctzll(pm);
+        const uint32_t ksL = (uint32_t)__builtin_amdgcn_readlane((int)ks, L);
+        const RT mx = lane_bcast<RT>(p.x, L), my = lane_bcast<RT>(p.y, L);
+        int found = P.max_reset_trials - 1;
+        for (int base = NSELF; base < P.max_reset_trials; base += 64) {
+            const int trial = base + (int)__lane_id();
+            RT cx, cy;
+            candidate(ksL, trial, cx, cy);
+            const unsigned long long okm = __ballot((trial < P.max_reset_trials) & far_enough(cx, cy, mx, my));
+            if (okm != 0ull) { found = base + __builtin_ctzll(okm); break; }
+        }
+        RT cx, cy;
+        candidate(ksL, found, cx, cy);
+        if ((int)__lane_id() == L) { ox = cx; oy = cy; }
     }
     g.x = stored<ST, RT>(Q.omin_x + (Q.omax_x - Q.omin_x) * rng_uniform<RT>(kg, 0u));  // PU:412-414
     g.y = stored<ST, RT>(Q.omin_y + (Q.omax_y - Q.omin_y) * rng_uniform<RT>(kg, 1u));
@@ -225,7 +264,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
         R2<RT> rp = p, rg = g;
         RT rox = o.x, roy = o.y;
         bool rwc;
-        const PushObs<RT> ro = push_reset_one<ST, RT, NOISE, FULL>(P, Q, T, env_global, c, rp, rg, rox, roy, rwc);
+        const PushObs<RT> ro = push_reset_one<ST, RT, NOISE, FULL>(P, Q, T, env_global, c, need, rp, rg, rox, roy, rwc);
         if (need) {
             p = rp; g = rg; v = R2<RT>{(RT)0, (RT)0}; acc = v; rot = v;
             o = Body<RT>{rox, roy, (RT)0, (RT)0, (RT)0, (RT)0};
