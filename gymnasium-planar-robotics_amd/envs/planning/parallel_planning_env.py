@@ -42,6 +42,9 @@ class VecBenchmarkPlanningParallelEnv:
             self._agent_obs = torch.zeros(e.num_envs, M, self.agent_obs_dim, dtype=e.dtype, device=e.device)
             self._agent_reward = torch.zeros(e.num_envs, M, dtype=e.dtype, device=e.device)
             self._action = torch.zeros(e.num_envs, 2 * M, dtype=e.dtype, device=e.device)
+            # the per-agent dict entries are fixed views of the gather kernel's two output tensors: built once
+            self._obs_views = {a: self._agent_obs[:, i, :] for i, a in enumerate(self.agents)}
+            self._rew_views = {a: self._agent_reward[:, i] for i, a in enumerate(self.agents)}
 
     def observation_space(self, agent: str) -> spaces.Box:
         return self._obs_space
@@ -55,9 +58,7 @@ class VecBenchmarkPlanningParallelEnv:
             _native.check(e._lib.gpr_agent_views(e._handle, e._obs['observation'].data_ptr(), e._obs['achieved_goal'].data_ptr(),
                                                  e._obs['desired_goal'].data_ptr(), e._reward.data_ptr(), self._agent_obs.data_ptr(),
                                                  self._agent_reward.data_ptr(), e._stream()), e._handle)
-        obs = {a: self._agent_obs[:, i, :] for i, a in enumerate(self.agents)}
-        rew = {a: self._agent_reward[:, i] for i, a in enumerate(self.agents)}
-        return obs, rew
+        return dict(self._obs_views), dict(self._rew_views)
 
     def reset(self, seed: int | None = None, options: dict | None = None):
         _, info = self.env.reset(seed=seed, options=options)
@@ -70,9 +71,12 @@ class VecBenchmarkPlanningParallelEnv:
         e = self.env
         if isinstance(actions, dict):
             assert set(actions) == set(self.agents), 'every agent must supply an action'
+            parts = [torch.as_tensor(actions[a], device=e.device) for a in self.agents]
             act = self._action.view(e.num_envs, self.num_movers, 2)
-            for i, a in enumerate(self.agents):
-                act[:, i, :] = torch.as_tensor(actions[a], device=e.device).to(e.dtype)
+            if all(t.dtype == e.dtype and tuple(t.shape) == (e.num_envs, 2) for t in parts):
+                torch.stack(parts, dim=1, out=act)  # one kernel for all agents
+            else:
+                act.copy_(torch.stack([t.reshape(e.num_envs, 2) for t in parts], dim=1))
             action = self._action
         else:
             action = torch.as_tensor(actions, device=e.device).to(e.dtype).reshape(e.num_envs, 2 * self.num_movers)
