@@ -649,6 +649,24 @@ template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_dist(RT x
         return PairSweep<RT, LPE, 1>::run(x, y);
     }
 }
+// smallest SQUARED pair distance this lane saw, in any precision and without a square root: the prefilter of the parity-mode
+// loops (a pair further apart than the limit plus the noise band cannot collide; only then is the literal sqrt form evaluated)
+template <typename RT, int LPE, int D> struct PairSweepSq {
+    static __device__ __forceinline__ RT run(RT x, RT y) {
+        const RT dx = x - rot<LPE, D>(x), dy = y - rot<LPE, D>(y);
+        const RT m = dx * dx + dy * dy;
+        if constexpr (D < LPE / 2) {
+            const RT rest = PairSweepSq<RT, LPE, D + 1>::run(x, y);
+            return rest < m ? rest : m;
+        } else {
+            return m;
+        }
+    }
+};
+template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_d2(RT x, RT y) {
+    if constexpr (LPE == 1) return Math<RT>::inf();
+    else return PairSweepSq<RT, LPE, 1>::run(x, y);
+}
 // compare a pair_min_dist result against a distance limit: <= (collision, BE:409) or < (goal spacing, PL:409)
 template <typename RT> __device__ __forceinline__ bool dist_le(RT m, RT lim) { return Math<RT>::literal ? (m <= lim) : (m <= lim * lim); }
 template <typename RT> __device__ __forceinline__ bool dist_lt(RT m, RT lim) { return Math<RT>::literal ? (m < lim) : (m < lim * lim); }

@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // the mover check is uncertain while |dist - thr| <= band_pair; on squared distances: |d2 - thr^2| <= 2 thr band + band^2
     const RT pair_thr = Math<RT>::literal ? C.max_csum_step : C.max_csum_step * C.max_csum_step;
     const RT pair_band = Math<RT>::literal ? band_pair : (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
+    const RT pair_near2 = (C.max_csum_step + band_pair) * (C.max_csum_step + band_pair) * (RT)1.000001;  // squared, with the noise band
 
     if constexpr (!Math<RT>::literal && SHAPE == 0) {
     // ---------------------------------------------------------------------------------------------------------------
@@ -458,8 +459,15 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 qacc.x = acc.x + C.dt * u.x;
                 qacc.y = acc.y + C.dt * u.y;
             } else {  // PL:442-443; mj_step with a plain force actuator of gain = mass: qacc = ctrl
-                R2<RT> vnext;
-                qacc = clamp_dyn<RT>(vn, C.v_max, a, C.dt, C.inv_dt, vnext);
+                // no lane within band_v of the speed limit: ensure_max_dyn_val returns the action unchanged (PL:636-637), and
+                // its square root and divisions (long sequences in double) are not evaluated
+                const RT t0 = v.x + C.dt * a.x, t1 = v.y + C.dt * a.y;
+                if (eager | (__ballot(!(t0 * t0 + t1 * t1 < vlim2)) != 0ull)) {
+                    R2<RT> vnext;
+                    qacc = clamp_dyn<RT>(vn, C.v_max, a, C.dt, C.inv_dt, vnext);
+                } else {
+                    qacc = a;
+                }
             }
             // MuJoCo's default (semi-implicit) Euler step on a free, undamped, gravity-compensated body (BE:878-883, BE:1132)
             if (!lane_of(frozen_m)) {
@@ -524,15 +532,20 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
                 wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step));
             }
-            const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
-            hraw = __ballot(md <= pair_thr);  // BE:409, inclusive
-            if (eager | ((__ballot(absr(md - pair_thr) <= pair_band) & live_m) != 0ull)) {
-                const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
-                hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+            hraw = 0ull;
+            if (eager | ((__ballot(pair_min_d2<RT, LPE>(p.x, p.y) <= pair_near2) & live_m) != 0ull)) {  // else: no pair can touch
+                const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
+                hraw = __ballot(md <= pair_thr);  // BE:409, inclusive
+                if (eager | ((__ballot(absr(md - pair_thr) <= pair_band) & live_m) != 0ull)) {
+                    const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
+                    hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+                }
             }
         } else {
             wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, p.x, p.y, cw_step));
-            hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(p.x, p.y), C.max_csum_step));
+            hraw = 0ull;
+            if ((__ballot(pair_min_d2<RT, LPE>(p.x, p.y) <= pair_near2) & live_m) != 0ull)
+                hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(p.x, p.y), C.max_csum_step));
         }
         // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle.
         // wc_m / mc_m collect the raw per-lane hits of not-yet-frozen envs; only the freeze decision needs the per-env OR now.
