@@ -110,6 +110,64 @@ def test_clamp_and_reward_golden(gpr):
         assert not e.compute_truncated(torch.zeros(5, 2 * M), torch.zeros(5, 2 * M)).any()
 
 
+def test_operators_large_fuzz_vs_oracle(gpr, oracle):
+    """beyond the 22k reference-labelled cases: 1.2 M wall checks on random layouts with holes, a third of them snapped onto
+    tile edges / onto "circle touches the edge" positions (the f64 operators must agree with the oracle bit for bit there
+    too), plus 200k rectangle pairs and segment pairs around touching configurations"""
+    rng = np.random.default_rng(2024)
+    total = 0
+    for it in range(12):
+        tx, ty = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        layout = (rng.random((tx, ty)) < 0.8).astype(np.int8)
+        layout[rng.integers(tx), rng.integers(ty)] = 1
+        box = it % 2 == 1
+        hs = float(rng.choice([0.12, 0.1]))
+        off, offw = float(rng.choice([0.0, 0.003])), float(rng.choice([0.0, 0.002]))
+        n = 100_000
+        qpos = np.zeros((n, 7)); qpos[:, 3] = 1.0
+        qpos[:, 0] = rng.uniform(-0.05, 2 * hs * tx + 0.05, n); qpos[:, 1] = rng.uniform(-0.05, 2 * hs * ty + 0.05, n)
+        if box:
+            size = np.array([0.07, 0.05])
+            yaw = rng.uniform(-np.pi, np.pi, n)
+            yaw[: n // 4] = rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2], n // 4)
+            qpos[:, 3] = np.cos(yaw / 2); qpos[:, 6] = np.sin(yaw / 2)
+            cs, r = size, size.max()
+        else:
+            cs, r = 0.11 * hs / 0.12, 0.11 * hs / 0.12
+        # snap a third of the positions to k * tile_width (+/- r, +/- safety offsets, +/- 1 ulp-ish)
+        k = n // 3
+        for d, t in ((0, tx), (1, ty)):
+            edge = 2 * hs * rng.integers(0, t + 1, k)
+            qpos[:k, d] = edge + rng.choice([0.0, r, -r, r + offw, -(r + offw), r + offw + off, -(r + offw + off)], k) + rng.choice([0.0, 1e-16, -1e-16, 1e-9, -1e-9], k)
+        cp = {'shape': 'box' if box else 'circle', 'size': cs, 'offset': off, 'offset_wall': offw}
+        env = _base_env(gpr, layout, 1, cp, tile_hs=hs)
+        ol = oracle.OracleLayout(layout, (hs, hs), 'box' if box else 'circle', off, offw)
+        for add in (False, True):
+            got = env.qpos_is_valid(qpos, cs, add).cpu().numpy()
+            want = ol.qpos_is_valid(qpos, cs, add)
+            # the reference raises for a centre above no tile (BE:514); the engine reports "invalid" and the oracle -1
+            assert np.array_equal(got != 0, want > 0), (it, add, int((got.astype(bool) != (want > 0)).sum()))
+            total += n
+        env.close()
+    assert total >= 1_200_000
+    G = gpr.geometry_2D_utils
+    n = 200_000
+    r1 = np.zeros((n, 7)); r2 = np.zeros((n, 7))
+    for r in (r1, r2):
+        yaw = rng.uniform(-np.pi, np.pi, n); yaw[: n // 4] = 0.0
+        r[:, 3] = np.cos(yaw / 2); r[:, 6] = np.sin(yaw / 2)
+    r1[:, :2] = rng.uniform(0, 1, (n, 2))
+    s1 = rng.uniform(0.03, 0.12, (n, 2)); s2 = rng.uniform(0.03, 0.12, (n, 2))
+    r2[:, :2] = r1[:, :2] + rng.uniform(-0.3, 0.3, (n, 2))
+    r2[: n // 4, 0] = r1[: n // 4, 0] + s1[: n // 4, 0] + s2[: n // 4, 0]; r2[: n // 4, 1] = r1[: n // 4, 1]  # axis-aligned, exactly touching
+    assert np.array_equal(G.check_rectangles_intersect(r1, r2, s1, s2).cpu().numpy(), oracle.check_rectangles_intersect(r1, r2, s1, s2))
+    assert np.array_equal(G.get_2D_rect_vertices(r1, s1).cpu().numpy(), oracle.get_2D_rect_vertices(r1, s1))
+    p1 = rng.uniform(0, 1, (n, 2)); p2 = p1 + rng.uniform(-0.3, 0.3, (n, 2)); q1 = rng.uniform(0, 1, (n, 2)); q2 = q1 + rng.uniform(-0.3, 0.3, (n, 2))
+    q1[: n // 5] = p1[: n // 5] + (p2[: n // 5] - p1[: n // 5]) * rng.uniform(0, 1, (n // 5, 1))  # q1 on the segment p1p2
+    q2[n // 5: n // 4] = p2[n // 5: n // 4]                                                      # shared end point
+    assert np.array_equal(G.check_line_segments_intersect(p1, p2, q1, q2).cpu().numpy(), oracle.check_line_segments_intersect(p1, p2, q1, q2))
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # closed-form trajectories (what the reference's CI asserts MuJoCo equals)
 # ----------------------------------------------------------------------------------------------------------------------
