@@ -149,6 +149,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-rollout-gather', action='store_true', help='skip the extra pass that times the rollout all-gather (N > 1)')
+    ap.add_argument('--gather-timeout', type=float, default=240.0, help='seconds the rollout all-gather pass may take (N > 1)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' + --single-device rehearses N > 1 on one GPU")
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     args = ap.parse_args()
@@ -162,39 +163,52 @@ def main():
 
     wall, gpu_ms, done_frac, nbytes = run_gpu(args, rank, local_rank, world, 1e-5)  # headline: the reference's default noise
     wall0, gpu_ms0, _, _ = run_gpu(args, rank, local_rank, world, 0.0)              # extra: sigma = 0
-    wall_g = None
+
+    E, M, K = args.envs_per_gpu, args.movers, args.steps
+    kernel_s = gpu_ms * 1e-3 / K  # HIP events around the timed region / launches: average duration of the step kernel
+    B = algorithmic_bytes_per_env_step(M)
+    achieved = B * E / kernel_s / 1e9
+    line = {
+        'metric': 'env-steps/sec, BenchmarkPlanningEnv 4 movers @ 65536 envs per MI355X',
+        'value': world * E * K / wall, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+        'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'f32': 'f32', 'f32_f64acc': 'f32 storage / f64 arithmetic', 'f64': 'f64'}[args.precision], 'data': 'synthetic',
+        'config': {
+            'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
+                        'std_noise 1e-5 (reference default), TimeLimit 50, same-step auto-reset, actions ~ U(-10, 10)',
+            'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
+            'done_fraction_per_step': done_frac,
+            'sigma0_env_steps_per_s': world * E * K / wall0, 'sigma0_kernel_us': gpu_ms0 * 1e3 / K,
+        },
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>', 'kernel_us': kernel_s * 1e6,
+                     'algorithmic_bytes_per_env_step': B},
+    }
+
     if world > 1 and not args.no_rollout_gather:
-        wall_g = run_gpu(args, rank, local_rank, world, 1e-5, gather=True)[0]                  # extra: + rollout all-gather
+        # extra pass: + the rollout all-gather. It moves GBs per flush over xGMI; a watchdog makes sure that the line above is
+        # printed (without this extra) even if that collective should not complete.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line['config']['rollout_gather'] = {'status': f'no result within {args.gather_timeout:.0f} s'}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.gather_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        wall_g = run_gpu(args, rank, local_rank, world, 1e-5, gather=True)[0]
+        dog.cancel()
+        flushes = max(1, (args.warmup % 50 + K) // 50)
+        line['config']['rollout_gather'] = {
+            'what': 'same run with ONE RCCL all_gather_into_tensor of every rank\'s [50, E, .] rollout buffer per 50 steps inside the timed region',
+            'env_steps_per_s': world * E * K / wall_g, 'bytes_per_rank_per_flush': nbytes,
+            'ms_per_flush': max(0.0, wall_g - wall) / flushes * 1e3,
+            'allgather_busbw_GBps': (world - 1) * nbytes / max(1e-9, (wall_g - wall) / flushes) / 1e9}
 
     if rank == 0:
-        E, M, K = args.envs_per_gpu, args.movers, args.steps
-        value = world * E * K / wall
-        kernel_s = gpu_ms * 1e-3 / K  # HIP events around the timed region / launches: average duration of the step kernel
-        B = algorithmic_bytes_per_env_step(M)
-        achieved = B * E / kernel_s / 1e9
-        line = {
-            'metric': 'env-steps/sec, BenchmarkPlanningEnv 4 movers @ 65536 envs per MI355X',
-            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
-            'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'f32_f64acc': 'f32 storage / f64 arithmetic', 'f64': 'f64'}[args.precision], 'data': 'synthetic',
-            'config': {
-                'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
-                            'std_noise 1e-5 (reference default), TimeLimit 50, same-step auto-reset, actions ~ U(-10, 10)',
-                'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
-                'done_fraction_per_step': done_frac,
-                'sigma0_env_steps_per_s': world * E * K / wall0, 'sigma0_kernel_us': gpu_ms0 * 1e3 / K,
-            },
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>', 'kernel_us': kernel_s * 1e6,
-                         'algorithmic_bytes_per_env_step': B},
-        }
-        if wall_g is not None:
-            flushes = max(1, (args.warmup % 50 + K) // 50)
-            line['config']['rollout_gather'] = {
-                'what': 'same run with ONE RCCL all_gather_into_tensor of every rank\'s [50, E, .] rollout buffer per 50 steps inside the timed region',
-                'env_steps_per_s': world * E * K / wall_g, 'bytes_per_rank_per_flush': nbytes,
-                'ms_per_flush': max(0.0, wall_g - wall) / flushes * 1e3,
-                'allgather_busbw_GBps': (world - 1) * nbytes / max(1e-9, (wall_g - wall) / flushes) / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
