@@ -99,6 +99,11 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
     static __device__ __forceinline__ int floor_int(float x) { return __float2int_rd(x); }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }  // 1 ulp reciprocal
+    static __device__ __forceinline__ void sincos_(float x, float &s, float &c) {  // v_sin / v_cos take revolutions
+        const float r = x * 0.15915494309189535f;
+        s = __builtin_amdgcn_sinf(r); c = __builtin_amdgcn_cosf(r);
+    }
 };
 template <> struct Math<double> {
     static constexpr bool literal = true;  // parity mode: the reference's operations in the reference's order
@@ -106,6 +111,8 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
     static __device__ __forceinline__ int floor_int(double x) { return __double2int_rd(x); }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static __device__ __forceinline__ double div_(double a, double b) { return a / b; }
+    static __device__ __forceinline__ void sincos_(double x, double &s, double &c) { sincos(x, &s, &c); }
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

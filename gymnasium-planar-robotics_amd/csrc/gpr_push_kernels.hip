@@ -12,23 +12,25 @@ template <typename RT> struct Body { RT x, y, th, vx, vy, w; };
 
 template <typename RT> __device__ __forceinline__ RT cross2(RT ax, RT ay, RT bx, RT by) { return ax * by - ay * bx; }
 
-// one control cycle of the two planar bodies (mirrors oracle/gpr_oracle.c push_cycle operation for operation)
+// one control cycle of the two planar bodies (mirrors oracle/gpr_oracle.c push_cycle operation for operation; the float build
+// takes its quotients through v_rcp_f32 and its sines / cosines from v_sin_f32 / v_cos_f32)
 template <typename RT> __device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT> &m, Body<RT> &o, RT ux, RT uy) {
     // 1. external forces
     m.vx = m.vx + dt * ux;
     m.vy = m.vy + dt * uy;
-    m.w = (m.w + dt * (Q.Kr * ((RT)0 - m.th)) * Q.inv_Im) / ((RT)1 + dt * Q.Dr * Q.inv_Im);
+    m.w = Math<RT>::div_(m.w + dt * (Q.Kr * ((RT)0 - m.th)) * Q.inv_Im, (RT)1 + dt * Q.Dr * Q.inv_Im);
     o.vx = o.vx * Q.damp_lin; o.vy = o.vy * Q.damp_lin;
-    o.w = o.w / Q.damp_rot_den;
+    o.w = Math<RT>::div_(o.w, Q.damp_rot_den);
     {
         const RT sp = Math<RT>::sqrt_(o.vx * o.vx + o.vy * o.vy);
-        if (sp <= Q.fric_dv) { o.vx = (RT)0; o.vy = (RT)0; } else { const RT k = (sp - Q.fric_dv) / sp; o.vx = o.vx * k; o.vy = o.vy * k; }
+        if (sp <= Q.fric_dv) { o.vx = (RT)0; o.vy = (RT)0; } else { const RT k = Math<RT>::div_(sp - Q.fric_dv, sp); o.vx = o.vx * k; o.vy = o.vy * k; }
         const RT aw = absr(o.w);
-        if (aw <= Q.fric_dw) o.w = (RT)0; else o.w = o.w * ((aw - Q.fric_dw) / aw);
+        if (aw <= Q.fric_dw) o.w = (RT)0; else o.w = o.w * Math<RT>::div_(aw - Q.fric_dw, aw);
     }
     // 2. contact: separating-axis test over the 4 face normals
     RT sm, cm, so, co;
-    if constexpr (sizeof(RT) == 8) { sincos(m.th, &sm, &cm); sincos(o.th, &so, &co); } else { sincosf(m.th, &sm, &cm); sincosf(o.th, &so, &co); }
+    Math<RT>::sincos_(m.th, sm, cm);
+    Math<RT>::sincos_(o.th, so, co);
     const RT ex4[4] = {cm, -sm, co, -so}, ey4[4] = {sm, cm, so, co};
     const RT dx = o.x - m.x, dy = o.y - m.y;
     RT best = Math<RT>::inf(), nx = (RT)0, ny = (RT)0;
@@ -73,8 +75,8 @@ template <typename RT> __device__ __forceinline__ void push_cycle(const PushCst<
                 RT rvx = (o.vx - o.w * roy) - (m.vx - m.w * rmy), rvy = (o.vy + o.w * rox) - (m.vy + m.w * rmx);
                 const RT rmn = cross2(rmx, rmy, nx, ny), ron = cross2(rox, roy, nx, ny);
                 const RT kn = Q.inv_mm + Q.inv_mo + rmn * rmn * Q.inv_Im + ron * ron * Q.inv_Io;
-                const RT bias = (dep[k] > (RT)0 ? dep[k] : (RT)0) / Q.tc;
-                RT dj = -((rvx * nx + rvy * ny) - bias) / kn;
+                const RT bias = Math<RT>::div_(dep[k] > (RT)0 ? dep[k] : (RT)0, Q.tc);
+                RT dj = Math<RT>::div_(-((rvx * nx + rvy * ny) - bias), kn);
                 RT jn_new = jn[k] + dj; if (jn_new < (RT)0) jn_new = (RT)0;
                 dj = jn_new - jn[k]; jn[k] = jn_new;
                 m.vx -= dj * nx * Q.inv_mm; m.vy -= dj * ny * Q.inv_mm; m.w -= dj * rmn * Q.inv_Im;
@@ -82,7 +84,7 @@ template <typename RT> __device__ __forceinline__ void push_cycle(const PushCst<
                 rvx = (o.vx - o.w * roy) - (m.vx - m.w * rmy); rvy = (o.vy + o.w * rox) - (m.vy + m.w * rmx);
                 const RT rmt = cross2(rmx, rmy, tx, ty), rot_ = cross2(rox, roy, tx, ty);
                 const RT kt = Q.inv_mm + Q.inv_mo + rmt * rmt * Q.inv_Im + rot_ * rot_ * Q.inv_Io;
-                RT djt = -(rvx * tx + rvy * ty) / kt;
+                RT djt = Math<RT>::div_(-(rvx * tx + rvy * ty), kt);
                 const RT lim = Q.mu * jn[k];
                 RT jt_new = jt[k] + djt;
                 if (jt_new > lim) jt_new = lim;
@@ -227,9 +229,19 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
         const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);
         Body<RT> m{p.x, p.y, rot.x, v.x, v.y, rot.y};
         bool frozen = reset_first;
+        const bool eager = P.eager_noise != 0;
         for (int cyc = 0; cyc < P.num_cycles; ++cyc) {
             // _mujoco_step_callback (PU:419-455): the same clamp chain as the planning env, on a noisy velocity read
-            const R2<RT> vn = noisy<RT, NOISE>(R2<RT>{m.vx, m.vy}, C.sig_v, key, 3u * (uint32_t)cyc);
+            // lazy noise as in the planning kernels: a reading is drawn only if some lane's comparison could depend on it
+            R2<RT> vn{m.vx, m.vy};
+            if constexpr (NOISE) {
+                bool need = true;
+                if constexpr (!JERK) {
+                    const RT t0 = m.vx + C.dt * a.x, t1 = m.vy + C.dt * a.y, lim = C.v_max - C.band_v;
+                    need = !(t0 * t0 + t1 * t1 < lim * lim) | (lim <= (RT)0);
+                }
+                if (eager | (__ballot(need & !frozen) != 0ull)) vn = noisy<RT, true>(vn, C.sig_v, key, 3u * (uint32_t)cyc);
+            }
             R2<RT> qacc, vnext;
             if constexpr (JERK) {
                 R2<RT> acc_tmp;
@@ -244,8 +256,17 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
             Body<RT> m2 = m, o2 = o;
             push_cycle<RT>(Q, C.dt, m2, o2, qacc.x, qacc.y);  // mj_step (BE:1882): engine model gpr-push-v1
             if (!frozen) { m = m2; o = o2; acc = qacc; }
-            const R2<RT> pw = noisy<RT, NOISE>(R2<RT>{m.x, m.y}, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
-            const bool w = !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);  // BE:1888-1894
+            bool w;  // BE:1888-1894
+            if constexpr (NOISE) {
+                bool unc;
+                w = !pos_valid_circle<RT, FULL, true>(T, P, m.x, m.y, cw_step, C.band_p, &unc);
+                if (eager | (__ballot(unc & !frozen) != 0ull)) {
+                    const R2<RT> pw = noisy<RT, true>(R2<RT>{m.x, m.y}, C.sig_p, key, 3u * (uint32_t)cyc + 1u);
+                    w = !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
+                }
+            } else {
+                w = !pos_valid_circle<RT, FULL>(T, P, m.x, m.y, cw_step);
+            }
             if (!frozen) { wc = w; frozen = w; }                                    // BE:1904-1905
         }
         p = R2<RT>{stored<ST, RT>(m.x), stored<ST, RT>(m.y)}; v = R2<RT>{stored<ST, RT>(m.vx), stored<ST, RT>(m.vy)};
