@@ -32,6 +32,21 @@ template <int KIND> __global__ void k(float *out, long long *clk, int iters) {
             u0 *= 0x7feb352du; u1 *= 0x7feb352du; u2 *= 0x7feb352du; u3 *= 0x7feb352du; u4 *= 0x7feb352du; u5 *= 0x7feb352du; u6 *= 0x7feb352du; u7 *= 0x7feb352du;
             a0 = __uint_as_float(u0 | 1); a1 = __uint_as_float(u1 | 1); a2 = __uint_as_float(u2 | 1); a3 = __uint_as_float(u3 | 1);
             a4 = __uint_as_float(u4 | 1); a5 = __uint_as_float(u5 | 1); a6 = __uint_as_float(u6 | 1); a7 = __uint_as_float(u7 | 1);
+        } else if constexpr (KIND == 7) {  // two dependent chains interleaved (a0 a1 a0 a1 ...)
+            a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c);
+            a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c);
+        } else if constexpr (KIND == 8) {  // four dependent chains interleaved
+            a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a2 = __builtin_fmaf(a2, b, c); a3 = __builtin_fmaf(a3, b, c);
+            a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a2 = __builtin_fmaf(a2, b, c); a3 = __builtin_fmaf(a3, b, c);
+        } else if constexpr (KIND == 9) {  // two chains, in pairs (a0 a0 a1 a1 ...): a dependent neighbour every other instruction
+            a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a1 = __builtin_fmaf(a1, b, c);
+            a0 = __builtin_fmaf(a0, b, c); a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a1 = __builtin_fmaf(a1, b, c);
+        } else if constexpr (KIND == 10) {  // ONE dependent chain of v_pk_fma_f32 (4 per iteration = 8 results)
+            p0 = __builtin_elementwise_fma(p0, pb, pc); p0 = __builtin_elementwise_fma(p0, pb, pc);
+            p0 = __builtin_elementwise_fma(p0, pb, pc); p0 = __builtin_elementwise_fma(p0, pb, pc);
+        } else if constexpr (KIND == 11) {  // the same 8 results as two dependent chains of plain v_fma_f32 (x chain, y chain)
+            a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c);
+            a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c);
         } else if constexpr (KIND == 6) {  // 8 x v_mov_dpp + add
             a0 += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(a1), 0x39, 0xF, 0xF, true));
             a1 += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(a2), 0x39, 0xF, 0xF, true));
@@ -74,5 +89,10 @@ int main() {
     run<4>("v_rsq_f32 x8", 8, out, clk);
     run<5>("v_mul_lo_u32 x8 (+or)", 16, out, clk);
     run<6>("mov_dpp+add x4", 8, out, clk);
+    run<10>("v_pk_fma_f32 x4 ONE chain", 4, out, clk);
+    run<11>("same 8 results: 2 fma chains", 8, out, clk);
+    run<7>("v_fma_f32 x8, 2 chains abab", 8, out, clk);
+    run<8>("v_fma_f32 x8, 4 chains abcd", 8, out, clk);
+    run<9>("v_fma_f32 x8, 2 chains aabb", 8, out, clk);
     return 0;
 }
