@@ -41,6 +41,19 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def make_sharded(env_cls, *args, num_envs_global: int, rank: int | None = None, world_size: int | None = None, **kwargs):
+    """This rank's shard of a ``num_envs_global``-env batch: ``env_cls(*args, num_envs=<shard size>, env_id_offset=<shard start>,
+    device=cuda:<LOCAL_RANK>, **kwargs)``. Random streams are keyed by global env id, so the shards of any world size reproduce the
+    single-device run env for env; there is nothing to exchange between shards in ``step()`` / ``reset()``."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get('RANK', '0'))
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else int(os.environ.get('WORLD_SIZE', '1'))
+    start, stop = shard_range(num_envs_global, rank, world_size)
+    kwargs.setdefault('device', torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))) if torch.cuda.is_available() else 'cpu')
+    return env_cls(*args, num_envs=stop - start, env_id_offset=start, **kwargs)
+
+
 @dataclass
 class _Field:
     name: str

@@ -129,6 +129,15 @@ def test_shard_range_partitions_every_env_once():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_make_sharded_covers_the_global_batch():
+    offs = []
+    for r in range(3):
+        e = gpr.distributed.make_sharded(gpr.VecBenchmarkPlanningEnv, np.ones((4, 4)), 2, num_envs_global=10, rank=r, world_size=3,
+                                         device='cpu', _host_only=True)
+        offs.append((e.env_id_offset, e.num_envs))
+    assert offs == [(0, 4), (4, 3), (7, 3)]
+
+
 def test_rollout_buffer_layout():
     import torch
     buf = gpr.distributed.RolloutBuffer(5, 8, 4, 8, dtype=torch.float32, device='cpu')
