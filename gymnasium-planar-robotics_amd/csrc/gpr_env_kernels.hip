@@ -346,6 +346,14 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // variables: the common cycle draws nothing)
     auto draw_index = [&](int cycle, uint32_t which) { uint32_t q = S * (uint32_t)cycle + which; asm volatile("" : "+s"(q)); return q; };
     int next_c = 0;  // wave-uniform: the first cycle at which the speed clamp has to be looked at again
+    // velocity-reading rows of this wavefront's needy lanes (see the clamp path); row 0 is all zeros
+    constexpr int VN_ROWS = 6;
+    __shared__ float2 vn_tab[BLOCK / 64][VN_ROWS + 1][64];
+    const int vn_wave = (int)(threadIdx.x >> 6);
+    vn_tab[vn_wave][0][__lane_id()] = make_float2(0.f, 0.f);
+    int vn_row = 0, vn_rows = 0;          // per lane: my row; wave-uniform: rows in use
+    unsigned long long vn_have = 0ull;    // lanes that own a row
+    bool vn_on = !every;                  // false: every lane draws per cycle (eager mode, > VN_ROWS needy lanes, > 64 cycles)
     const R2<RT> q0{p0.x - (RT)0.5 * (C.gx0 + C.gx1), p0.y - (RT)0.5 * (C.gy0 + C.gy1)};
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
@@ -353,14 +361,41 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         if (cyc >= next_c) {
             R2<RT> t{v.x + dtl.x, v.y + dtl.y};
             RT n2 = t.x * t.x + t.y * t.y;
-            if (__ballot(!(n2 < vneed2_l)) == 0ull) {
+            const unsigned long long needm = __ballot(!(n2 < vneed2_l));
+            if (needm == 0ull) {
                 const int k = __ballot(!(n2 < c1r)) != 0ull ? 0 : __ballot(!(n2 < c2r)) != 0ull ? KC1 : __ballot(!(n2 < c3r)) != 0ull ? KC2 : KC3;
                 next_c = cyc + 1 + k;
             } else {
                 R2<RT> nv{(RT)0, (RT)0};
                 if constexpr (NOISE) {
-                    const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));  // PL:430
-                    nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
+                    // Velocity readings (PL:430) matter only to the lanes inside the clamp band -- one or two lanes of the
+                    // wavefront, the same ones for the rest of the env-step -- and a reading is a pure function of (lane key,
+                    // cycle). So when a lane first needs one, the 64 lanes draw, once, THAT lane's readings for cycles 0..63 (lane
+                    // c draws cycle c) into a row of LDS; from then on a cycle costs every lane one ds_read (its own row, or the
+                    // all-zero row) instead of a Box-Muller draw of which 63 results are not looked at. The kernel lasts as long
+                    // as its slowest wavefront, and that is one that clamps in all 40 cycles: this is where its time goes.
+                    const unsigned long long fresh = needm & ~vn_have;
+                    if (!(vn_on & (fresh == 0ull))) {
+                        if (vn_on) {
+                            for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
+                                if ((vn_rows == VN_ROWS) | (P.num_cycles > 64)) { vn_on = false; break; }
+                                const int L = __builtin_ctzll(f);
+                                const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+                                const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
+                                ++vn_rows;
+                                vn_tab[vn_wave][vn_rows][__lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
+                                if ((int)__lane_id() == L) vn_row = vn_rows;
+                                vn_have |= 1ull << L;
+                            }
+                        }
+                    }
+                    if (vn_on) {
+                        const float2 r = vn_tab[vn_wave][vn_row][cyc];
+                        nv.x = r.x; nv.y = r.y;
+                    } else {
+                        const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
+                        nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
+                    }
                     t.x += nv.x; t.y += nv.y;
                     n2 = t.x * t.x + t.y * t.y;
                 }
