@@ -375,7 +375,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                     // all-zero row) instead of a Box-Muller draw of which 63 results are not looked at. The kernel lasts as long
                     // as its slowest wavefront, and that is one that clamps in all 40 cycles: this is where its time goes.
                     const unsigned long long fresh = needm & ~vn_have;
-                    if (!(vn_on & (fresh == 0ull))) {
+                    if (vn_on & (fresh == 0ull)) {  // the steady state: one scalar decision, one LDS read
+                        const float2 r = vn_tab[vn_wave][vn_row][cyc];
+                        nv.x = r.x; nv.y = r.y;
+                    } else {
                         if (vn_on) {
                             for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
                                 if ((vn_rows == VN_ROWS) | (P.num_cycles > 64)) { vn_on = false; break; }
@@ -388,13 +391,13 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                                 vn_have |= 1ull << L;
                             }
                         }
-                    }
-                    if (vn_on) {
-                        const float2 r = vn_tab[vn_wave][vn_row][cyc];
-                        nv.x = r.x; nv.y = r.y;
-                    } else {
-                        const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
-                        nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
+                        if (vn_on) {
+                            const float2 r = vn_tab[vn_wave][vn_row][cyc];
+                            nv.x = r.x; nv.y = r.y;
+                        } else {
+                            const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
+                            nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
+                        }
                     }
                     t.x += nv.x; t.y += nv.y;
                     n2 = t.x * t.x + t.y * t.y;
