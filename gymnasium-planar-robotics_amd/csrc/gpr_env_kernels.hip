@@ -237,9 +237,22 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
     const int64_t env_global = P.env_id_offset + envc;
 
-    __shared__ int reset_count, reset_list[BLOCK];  // envs of this block that need a reset (local env index * 2 + "reset only")
-    if (threadIdx.x == 0) reset_count = 0;
     const int64_t env_block_base = (int64_t)blockIdx.x * (BLOCK / LPE);
+    // RESET QUEUE of the block. A reset is a pure function of (seed, tick, env id): it does not need the env's final state, only
+    // the knowledge THAT the env ends in this call -- and that is known early: a TimeLimit truncation (and a next-step-mode
+    // reset) before the first cycle, a collision in the cycle it happens. An env is queued the moment it is known to end
+    // (local env index * 2 + "reset only"), and every wavefront that is through with its own cycles serves the queue, so that
+    // the resets of the block overlap with the cycles of its slowest wavefront (one that clamps in all 40 cycles takes twice
+    // as long as a quiet one) instead of waiting for it. Entries: -1 = reserved but not written yet.
+    __shared__ int reset_count, reset_claimed, reset_list[BLOCK];
+    reset_list[threadIdx.x] = -1;
+    if (threadIdx.x == 0) { reset_count = 0; reset_claimed = 0; }
+    bool queued = false;
+    auto enqueue = [&](bool reset_only) {
+        const int slot = atomicAdd(&reset_count, 1);
+        __hip_atomic_store(&reset_list[slot], (int)(envc - env_block_base) * 2 + (int)reset_only, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        queued = true;
+    };
 
     // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
     R2<RT> a = load2<ST, RT>(P.action, idx);
@@ -264,6 +277,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     a.y = fmin(fmax(a.y, -lim), lim);
 
     const bool reset_first = (P.autoreset == 2) & (el < 0);  // next-step autoreset: this call only resets the env
+    {
+        const bool trunc_known = (P.autoreset == 1) & (P.max_episode_steps > 0) & (el + 1 >= P.max_episode_steps);
+        if (live & (mv == 0) & (reset_first | trunc_known)) enqueue(reset_first);
+    }
     // per-env decisions are kept as wave masks (one bit per lane, identical within an env group): scalar registers
     unsigned long long frozen_m = __ballot(reset_first), wc_m = 0ull, mc_m = 0ull;
     const unsigned long long live_m = __ballot(live);
@@ -467,7 +484,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             mc_m |= hraw;
             const unsigned long long nf = group_or<LPE>(wraw | hraw);
             frozen_m |= nf;
-            if (lane_of(nf)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
+            if (lane_of(nf)) {
+                dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT();
+                if ((P.autoreset == 1) & live & (mv == 0) & !queued) enqueue(false);  // a collision ends the env (PL:478): reset it
+            }
         }
     }
     p.x = p0.x + dp.x; p.y = p0.y + dp.y;
@@ -624,20 +644,30 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             store_obs<ST, RT, JERK>(P, P.final_obs, P.final_ag, P.final_dg, envc, mv, idx, o.vel, acc, o.ag, g, true);
         }
         if ((mv == 0) & !reset_first) store_env_scalars<ST, RT>(P, envc, el_new, o.reward, o.terminated, trunc, o.is_success, mc, wc);
-        if (need & (mv == 0)) reset_list[atomicAdd(&reset_count, 1)] = (int)(envc - env_block_base) * 2 + (int)reset_first;
+        if (need & (mv == 0) & !queued) enqueue(reset_first);  // (a success, or a collision found by the generic loop)
     }
 
-    // RESET PASS. A reset is a pure function of (seed, tick, env id), so the envs that need one are handed over as a list of
-    // env ids and packed densely into as few wavefronts of the block as they fill (64 / LPE envs each): with ~14 % of the envs
-    // ending per step, one wavefront resets what would otherwise keep all four busy with rejection sampling for one or two
-    // envs each.
-    __syncthreads();
-    const int n_reset = reset_count;
-    constexpr int EPW = 64 / LPE;  // envs per wavefront
-    if constexpr (LPE >= 8 && SHAPE == 0) {
-        // wide env groups: one env per wavefront at a time, its 64 / LPE lane groups try 64 / LPE rejection trials in parallel
-        for (int i = (int)(threadIdx.x >> 6); i < n_reset; i += BLOCK / 64) {
-            const int entry = reset_list[i];
+    // SERVING THE QUEUE: claim up to 64 / LPE queued envs at a time (one for wide env groups, whose lane groups try rejection
+    // trials in parallel) until nothing unclaimed is left. Whatever is queued later is served by a wavefront that finishes
+    // later -- at the latest by the one that queued it.
+    constexpr int EPW = (LPE >= 8 && SHAPE == 0) ? 1 : 64 / LPE;  // envs per claim
+    for (;;) {
+        int base = 0, n = 0;
+        if ((threadIdx.x & 63) == 0) {
+            for (;;) {
+                const int c0 = __hip_atomic_load(&reset_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int cnt = __hip_atomic_load(&reset_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n = cnt - c0 < EPW ? cnt - c0 : EPW;
+                if (n <= 0) { n = 0; break; }
+                if (atomicCAS(&reset_claimed, c0, c0 + n) == c0) { base = c0; break; }
+            }
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        n = __builtin_amdgcn_readfirstlane(n);
+        if (n == 0) break;
+        if constexpr (LPE >= 8 && SHAPE == 0) {
+            int entry;
+            do { entry = __hip_atomic_load(&reset_list[base], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
             const int64_t renv = env_block_base + (entry >> 1);
             const bool rfirst = (entry & 1) != 0;
             R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
@@ -653,29 +683,28 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
                 if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
             }
-        }
-        return;
-    }
-    for (int base = (int)(threadIdx.x >> 6) * EPW; base < n_reset; base += (BLOCK / 64) * EPW) {
-        const int slot = base + (int)(threadIdx.x & 63) / LPE;
-        const bool have = slot < n_reset;
-        const int entry = reset_list[have ? slot : base];
-        const int64_t renv = env_block_base + (entry >> 1);
-        const bool rfirst = (entry & 1) != 0;
-        const bool rlive = have & (mv < M);
-        R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
-        bool rwc, rmc;
-        const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, rp, rg, rwc, rmc);
-        if (rlive) {
-            const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
-            const R2<RT> zero{(RT)0, (RT)0};
-            store2<ST, RT>(P.pos, ridx, rp);
-            store2<ST, RT>(P.vel, ridx, zero);
-            if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
-            store2<ST, RT>(P.goal, ridx, rg);
-            store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
-            // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
-            if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
+        } else {
+            const int slot = (int)(threadIdx.x & 63) / LPE;
+            const bool have = slot < n;
+            int entry;
+            do { entry = __hip_atomic_load(&reset_list[base + (have ? slot : 0)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
+            const int64_t renv = env_block_base + (entry >> 1);
+            const bool rfirst = (entry & 1) != 0;
+            const bool rlive = have & (mv < M);
+            R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+            bool rwc, rmc;
+            const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, rp, rg, rwc, rmc);
+            if (rlive) {
+                const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
+                const R2<RT> zero{(RT)0, (RT)0};
+                store2<ST, RT>(P.pos, ridx, rp);
+                store2<ST, RT>(P.vel, ridx, zero);
+                if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
+                store2<ST, RT>(P.goal, ridx, rg);
+                store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
+                // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
+                if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
+            }
         }
     }
 }
