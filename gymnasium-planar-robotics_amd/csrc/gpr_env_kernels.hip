@@ -244,9 +244,9 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // (local env index * 2 + "reset only"), and every wavefront that is through with its own cycles serves the queue, so that
     // the resets of the block overlap with the cycles of its slowest wavefront (one that clamps in all 40 cycles takes twice
     // as long as a quiet one) instead of waiting for it. Entries: -1 = reserved but not written yet.
-    __shared__ int reset_count, reset_claimed, reset_list[BLOCK];
+    __shared__ int reset_count, reset_claimed, waves_through, reset_list[BLOCK];
     reset_list[threadIdx.x] = -1;
-    if (threadIdx.x == 0) { reset_count = 0; reset_claimed = 0; }
+    if (threadIdx.x == 0) { reset_count = 0; reset_claimed = 0; waves_through = 0; }
     bool queued = false;
     auto enqueue = [&](bool reset_only) {
         const int slot = atomicAdd(&reset_count, 1);
@@ -650,15 +650,26 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // SERVING THE QUEUE: claim up to 64 / LPE queued envs at a time (one for wide env groups, whose lane groups try rejection
     // trials in parallel) until nothing unclaimed is left. Whatever is queued later is served by a wavefront that finishes
     // later -- at the latest by the one that queued it.
+    // A wavefront that finds the queue empty stays (sleeping between looks) until every wavefront of the block is through with
+    // its cycles: the envs the slowest wavefront queues while it is still cycling are then reset before it is done, and
+    // nothing but its own last-minute entries is left for the end. Every wavefront gets here without waiting for anything, so
+    // the wait ends.
     constexpr int EPW = (LPE >= 8 && SHAPE == 0) ? 1 : 64 / LPE;  // envs per claim
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
         int base = 0, n = 0;
         if ((threadIdx.x & 63) == 0) {
             for (;;) {
+                const int all_through = __hip_atomic_load(&waves_through, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == BLOCK / 64;
                 const int c0 = __hip_atomic_load(&reset_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int cnt = __hip_atomic_load(&reset_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 n = cnt - c0 < EPW ? cnt - c0 : EPW;
-                if (n <= 0) { n = 0; break; }
+                if (n <= 0) {
+                    n = 0;
+                    if (all_through) break;  // (read before the counters: nothing can be queued after it was seen set)
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
                 if (atomicCAS(&reset_claimed, c0, c0 + n) == c0) { base = c0; break; }
             }
         }
