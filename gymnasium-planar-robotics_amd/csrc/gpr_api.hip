@@ -36,6 +36,7 @@ struct gpr_env {
     uint64_t seed = 0, tick = 0;
     int lpe = 1;
     bool push_ready = false;
+    size_t wave_timing_words = 0;
     PushCst<float> push_f{};
     PushCst<double> push_d{};
     PushPtrs push_ptrs{};
@@ -321,7 +322,16 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     P.layout_full = full;
     // validation switch: GPR_EAGER_NOISE=1 draws every noise sample of every cycle instead of only those that can matter
     const char *eager = std::getenv("GPR_EAGER_NOISE");
-    P.eager_noise = eager && eager[0] == '1';  // also runs both collision checks on every cycle (no skip ladder)
+    P.eager_noise = eager && eager[0] == '1';
+    P.wave_timing = nullptr;
+#ifdef GPR_WAVE_TIMING
+    // debug build: per-wavefront clocks of the last step kernel, dumped to $GPR_WAVE_TIMING (a file name) by gpr_destroy
+    if (std::getenv("GPR_WAVE_TIMING")) {
+        e->wave_timing_words = (size_t)((c.num_envs * e->lpe + 63) / 64) * 8;
+        if (hipMalloc(&P.wave_timing, e->wave_timing_words * 4) == hipSuccess) (void)hipMemset(P.wave_timing, 0, e->wave_timing_words * 4);
+        else P.wave_timing = nullptr;
+    }
+#endif  // also runs both collision checks on every cycle (no skip ladder)
     fill_cst<float>(*e, P.cf);
     fill_cst<double>(*e, P.cd);
     *out_env = e;
@@ -330,6 +340,14 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
 
 void gpr_destroy(gpr_env *env) {
     if (!env) return;
+#ifdef GPR_WAVE_TIMING
+    if (env->base.wave_timing) {
+        std::vector<unsigned int> h(env->wave_timing_words);
+        (void)hipMemcpy(h.data(), env->base.wave_timing, h.size() * 4, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(std::getenv("GPR_WAVE_TIMING"), "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+        (void)hipFree(env->base.wave_timing);
+    }
+#endif
     if (env->tab_f32.dev) (void)hipFree(env->tab_f32.dev);
     if (env->tab_f64.dev) (void)hipFree(env->tab_f64.dev);
     delete env;

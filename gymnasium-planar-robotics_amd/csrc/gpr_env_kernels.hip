@@ -237,6 +237,13 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
     const int64_t env_global = P.env_id_offset + envc;
 
+#ifdef GPR_WAVE_TIMING
+    const long long wt0 = __builtin_amdgcn_s_memtime();
+    int wt_clamp = 0, wt_near = 0, wt_served = 0;
+#define GPR_WT(x) x
+#else
+#define GPR_WT(x)
+#endif
     const int64_t env_block_base = (int64_t)blockIdx.x * (BLOCK / LPE);
     // RESET QUEUE of the block. A reset is a pure function of (seed, tick, env id): it does not need the env's final state, only
     // the knowledge THAT the env ends in this call -- and that is known early: a TimeLimit truncation (and a next-step-mode
@@ -383,6 +390,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 const int k = __ballot(!(n2 < c1r)) != 0ull ? 0 : __ballot(!(n2 < c2r)) != 0ull ? KC1 : __ballot(!(n2 < c3r)) != 0ull ? KC2 : KC3;
                 next_c = cyc + 1 + k;
             } else {
+                GPR_WT(++wt_clamp;)
                 R2<RT> nv{(RT)0, (RT)0};
                 if constexpr (NOISE) {
                     // Velocity readings (PL:430) matter only to the lanes inside the clamp band -- one or two lanes of the
@@ -448,6 +456,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             sp_p = __ballot(md <= p0r);
         }
         if ((sp_w | sp_p) == 0ull) continue;
+        GPR_WT(++wt_near;)
         p.x = p0.x + dp.x; p.y = p0.y + dp.y;
         // ---- something is close: the exact checks, each on its own noisy position read ----
         unsigned long long wraw, hraw = 0ull;
@@ -655,6 +664,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // nothing but its own last-minute entries is left for the end. Every wavefront gets here without waiting for anything, so
     // the wait ends.
     constexpr int EPW = (LPE >= 8 && SHAPE == 0) ? 1 : 64 / LPE;  // envs per claim
+    GPR_WT(const long long wt1 = __builtin_amdgcn_s_memtime();)
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
         int base = 0, n = 0;
@@ -676,6 +686,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         base = __builtin_amdgcn_readfirstlane(base);
         n = __builtin_amdgcn_readfirstlane(n);
         if (n == 0) break;
+        GPR_WT(wt_served += n;)
         if constexpr (LPE >= 8 && SHAPE == 0) {
             int entry;
             do { entry = __hip_atomic_load(&reset_list[base], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
@@ -718,6 +729,15 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             }
         }
     }
+#ifdef GPR_WAVE_TIMING
+    if (P.wave_timing && (threadIdx.x & 63) == 0) {  // clocks: cycles + own stores | queue service incl. waiting; counts
+        const long long wt2 = __builtin_amdgcn_s_memtime();
+        unsigned int *d = P.wave_timing + 8 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+        d[0] = (unsigned)(wt1 - wt0); d[1] = (unsigned)(wt2 - wt1); d[2] = (unsigned)wt_clamp; d[3] = (unsigned)wt_near; d[4] = (unsigned)wt_served;
+        d[5] = (unsigned)(wt0 & 0xffffffffu); d[6] = (unsigned)(wt0 >> 32);
+    }
+#endif
+#undef GPR_WT
 }
 
 // -----------------------------------------------------------------------------------------------------------------
