@@ -375,9 +375,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     __shared__ float2 vn_tab[BLOCK / 64][VN_ROWS + 1][64];
     const int vn_wave = (int)(threadIdx.x >> 6);
     vn_tab[vn_wave][0][__lane_id()] = make_float2(0.f, 0.f);
-    int vn_row = 0, vn_rows = 0;          // per lane: my row; wave-uniform: rows in use
-    unsigned long long vn_have = 0ull;    // lanes that own a row
+    const float2 *vn_ptr = &vn_tab[vn_wave][0][0];  // per lane: my row (row 0 until the lane needs readings)
+    int vn_rows = 0;                                 // wave-uniform: rows in use
     bool vn_on = !every;                  // false: every lane draws per cycle (eager mode, > VN_ROWS needy lanes, > 64 cycles)
+    unsigned long long vn_uncovered = ~0ull;  // lanes that may NOT simply read their row: no row of their own yet (or !vn_on: all)
     const R2<RT> q0{p0.x - (RT)0.5 * (C.gx0 + C.gx1), p0.y - (RT)0.5 * (C.gy0 + C.gy1)};
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
@@ -399,25 +400,25 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                     // c draws cycle c) into a row of LDS; from then on a cycle costs every lane one ds_read (its own row, or the
                     // all-zero row) instead of a Box-Muller draw of which 63 results are not looked at. The kernel lasts as long
                     // as its slowest wavefront, and that is one that clamps in all 40 cycles: this is where its time goes.
-                    const unsigned long long fresh = needm & ~vn_have;
-                    if (vn_on & (fresh == 0ull)) {  // the steady state: one scalar decision, one LDS read
-                        const float2 r = vn_tab[vn_wave][vn_row][cyc];
+                    const unsigned long long fresh = needm & vn_uncovered;
+                    if (fresh == 0ull) {  // the steady state: one scalar decision, one LDS read
+                        const float2 r = vn_ptr[cyc];
                         nv.x = r.x; nv.y = r.y;
                     } else {
                         if (vn_on) {
                             for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
-                                if ((vn_rows == VN_ROWS) | (P.num_cycles > 64)) { vn_on = false; break; }
+                                if ((vn_rows == VN_ROWS) | (P.num_cycles > 64)) { vn_on = false; vn_uncovered = ~0ull; break; }
                                 const int L = __builtin_ctzll(f);
                                 const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
                                 const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
                                 ++vn_rows;
                                 vn_tab[vn_wave][vn_rows][__lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
-                                if ((int)__lane_id() == L) vn_row = vn_rows;
-                                vn_have |= 1ull << L;
+                                if ((int)__lane_id() == L) vn_ptr = &vn_tab[vn_wave][vn_rows][0];
+                                vn_uncovered &= ~(1ull << L);
                             }
                         }
                         if (vn_on) {
-                            const float2 r = vn_tab[vn_wave][vn_row][cyc];
+                            const float2 r = vn_ptr[cyc];
                             nv.x = r.x; nv.y = r.y;
                         } else {
                             const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
