@@ -386,6 +386,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         if (cyc >= next_c) {
             R2<RT> t{v.x + dtl.x, v.y + dtl.y};
             RT n2 = t.x * t.x + t.y * t.y;
+            float2 vn_r = make_float2(0.f, 0.f);
+            if constexpr (NOISE) vn_r = vn_ptr[cyc & 63];  // issued here so that its LDS latency hides behind the tests below
             const unsigned long long needm = __ballot(!(n2 < vneed2_l));
             if (needm == 0ull) {
                 const int k = __ballot(!(n2 < c1r)) != 0ull ? 0 : __ballot(!(n2 < c2r)) != 0ull ? KC1 : __ballot(!(n2 < c3r)) != 0ull ? KC2 : KC3;
@@ -401,9 +403,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                     // all-zero row) instead of a Box-Muller draw of which 63 results are not looked at. The kernel lasts as long
                     // as its slowest wavefront, and that is one that clamps in all 40 cycles: this is where its time goes.
                     const unsigned long long fresh = needm & vn_uncovered;
-                    if (fresh == 0ull) {  // the steady state: one scalar decision, one LDS read
-                        const float2 r = vn_ptr[cyc];
-                        nv.x = r.x; nv.y = r.y;
+                    if (fresh == 0ull) {  // the steady state: one scalar decision, the reading is already on its way
+                        nv.x = vn_r.x; nv.y = vn_r.y;
                     } else {
                         if (vn_on) {
                             for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
