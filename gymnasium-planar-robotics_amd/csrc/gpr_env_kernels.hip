@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 
 #ifdef GPR_WAVE_TIMING
     const long long wt0 = __builtin_amdgcn_s_memtime();
-    int wt_clamp = 0, wt_near = 0, wt_served = 0;
+    int wt_clamp = 0, wt_near = 0, wt_served = 0, wt_rows = 0, wt_direct = 0, wt_due = 0;
 #define GPR_WT(x) x
 #else
 #define GPR_WT(x)
@@ -384,6 +384,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
         R2<RT> dvn{dv.x + dtl.x, dv.y + dtl.y};
         if (cyc >= next_c) {
+            GPR_WT(++wt_due;)
             R2<RT> t{v.x + dtl.x, v.y + dtl.y};
             RT n2 = t.x * t.x + t.y * t.y;
             float2 vn_r = make_float2(0.f, 0.f);
@@ -413,6 +414,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                                 const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
                                 const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
                                 ++vn_rows;
+                                GPR_WT(++wt_rows;)
                                 vn_tab[vn_wave][vn_rows][__lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
                                 if ((int)__lane_id() == L) vn_ptr = &vn_tab[vn_wave][vn_rows][0];
                                 vn_uncovered &= ~(1ull << L);
@@ -422,6 +424,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                             const float2 r = vn_ptr[cyc];
                             nv.x = r.x; nv.y = r.y;
                         } else {
+                            GPR_WT(++wt_direct;)
                             const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
                             nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
                         }
@@ -736,7 +739,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         const long long wt2 = __builtin_amdgcn_s_memtime();
         unsigned int *d = P.wave_timing + 8 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
         d[0] = (unsigned)(wt1 - wt0); d[1] = (unsigned)(wt2 - wt1); d[2] = (unsigned)wt_clamp; d[3] = (unsigned)wt_near; d[4] = (unsigned)wt_served;
-        d[5] = (unsigned)(wt0 & 0xffffffffu); d[6] = (unsigned)(wt0 >> 32);
+        d[5] = (unsigned)wt_rows; d[6] = (unsigned)wt_direct; d[7] = (unsigned)wt_due;
     }
 #endif
 #undef GPR_WT

@@ -21,3 +21,10 @@ for lo, hi in ((0, 0), (1, 10), (11, 39), (40, 40)):
     m = (clamp >= lo) & (clamp <= hi)
     if m.any(): print(f'  wavefronts clamping in {lo}-{hi} cycles: {m.mean() * 100:5.1f} %, cycles phase mean {cyc[m].mean():.0f}')
 print(f'  envs served per wavefront: mean {served.mean():.1f}; near-collision cycles per wavefront: mean {near.mean():.1f}')
+rows, direct, due = d[:, 5], d[:, 6], d[:, 7]
+top = np.argsort(-cyc)[:40]
+print('  the slowest wavefronts (cycles phase): clocks / clamp cycles / clamp looks / near cycles / LDS rows built / per-cycle draws')
+for i in top[:8]: print(f'    {cyc[i]:7.0f} {clamp[i]:3.0f} {due[i]:3.0f} {near[i]:3.0f} {rows[i]:2.0f} {direct[i]:3.0f}')
+A = np.stack([np.ones_like(cyc), clamp, near, rows, direct, due - clamp], axis=1)
+coef, *_ = np.linalg.lstsq(A, cyc, rcond=None)
+print('  least squares: cycles phase = %.0f + %.0f per clamp cycle + %.0f per near cycle + %.0f per row built + %.0f per per-cycle draw + %.0f per idle clamp look' % tuple(coef))
