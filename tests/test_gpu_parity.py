@@ -386,10 +386,14 @@ def test_lazy_noise_is_exact(gpr, monkeypatch):
     """The kernels skip a noise draw when no possible value of it could change the outcome of the comparison it feeds.
     GPR_EAGER_NOISE=1 (read at env creation) draws everything: both must produce bit-identical rollouts."""
     box = {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.001}
-    for layout, M, prec, cp in ((np.ones((6, 6)), 4, 'f32', None), (HOLES, 3, 'f32', None), (np.ones((5, 5)), 2, 'f64', None),
-                                (np.ones((4, 6)), 2, 'f32', None), (HOLES, 4, 'f32', box), (np.ones((4, 4)), 3, 'f64', box)):
+    for layout, M, prec, cp, ncyc in ((np.ones((6, 6)), 4, 'f32', None, 40), (HOLES, 3, 'f32', None, 40), (np.ones((5, 5)), 2, 'f64', None, 40),
+                                      (np.ones((4, 6)), 2, 'f32', None, 40), (HOLES, 4, 'f32', box, 40), (np.ones((4, 4)), 3, 'f64', box, 40),
+                                      (np.ones((6, 6)), 4, 'f32', None, 100),   # more cycles than an LDS row of readings holds
+                                      (np.ones((8, 8)), 1, 'f32', None, 40),    # one mover: no pair check at all
+                                      (np.ones((10, 10)), 16, 'f32', None, 7)):  # 16 lanes per env, odd cycle count
         E = 2048 if prec == 'f32' else 256
-        kw = dict(num_envs=E, precision=prec, std_noise=np.array([2e-5, 1e-5, 0.0]), learn_jerk=(prec == 'f64'), collision_params=cp)
+        kw = dict(num_envs=E, precision=prec, std_noise=np.array([2e-5, 1e-5, 0.0]), learn_jerk=(prec == 'f64'), collision_params=cp,
+                  num_cycles=ncyc)
         monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
         lazy = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
         monkeypatch.setenv('GPR_EAGER_NOISE', '1')
