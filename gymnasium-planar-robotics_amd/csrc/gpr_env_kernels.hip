@@ -507,6 +507,16 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     p.x = p0.x + dp.x; p.y = p0.y + dp.y;
 #undef GPR_LANE_OUT
     } else {
+    // velocity-reading rows (parity-mode loop), see the clamp path of the throughput loop; row 0 is all zeros
+    constexpr int VG_ROWS = 6;
+    typedef typename V2<RT>::type VgVec;
+    __shared__ VgVec vg_tab[(Math<RT>::literal && NOISE) ? BLOCK / 64 : 1][(Math<RT>::literal && NOISE) ? VG_ROWS + 1 : 1][(Math<RT>::literal && NOISE) ? 64 : 1];
+    const int vg_wave = (Math<RT>::literal && NOISE) ? (int)(threadIdx.x >> 6) : 0;
+    if constexpr (Math<RT>::literal && NOISE) { VgVec z; z.x = (RT)0; z.y = (RT)0; vg_tab[vg_wave][0][__lane_id()] = z; }
+    const VgVec *vg_ptr = &vg_tab[vg_wave][0][0];
+    int vg_rows = 0;
+    bool vg_on = true;
+    unsigned long long vg_uncovered = ~0ull;
     for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882)
         if constexpr (Math<RT>::literal) {
@@ -518,7 +528,35 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 const RT t0 = v.x + C.dt * acc_tmp.x, t1 = v.y + C.dt * acc_tmp.y;
                 const RT lim = C.v_max - C.band_v;
                 const bool need = !(t0 * t0 + t1 * t1 < lim * lim) | (lim <= (RT)0);
-                if (eager | (__ballot(need) != 0ull)) vn = noisy<RT, true>(v, C.sig_v, key, S * (uint32_t)cyc);  // PL:430
+                const unsigned long long needm = __ballot(need);
+                if (eager) {
+                    vn = noisy<RT, true>(v, C.sig_v, key, S * (uint32_t)cyc);  // PL:430
+                } else if (needm != 0ull) {
+                    // as in the throughput loop: the readings of a needy lane for cycles 0..63 are drawn once, by the 64 lanes,
+                    // into a row of LDS (a double-precision Box-Muller draw is several hundred instructions)
+                    const unsigned long long fresh = needm & vg_uncovered;
+                    if (fresh != 0ull) {
+                        if (vg_on) {
+                            for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
+                                if ((vg_rows == VG_ROWS) | (P.num_cycles > 64)) { vg_on = false; vg_uncovered = ~0ull; break; }
+                                const int L = __builtin_ctzll(f);
+                                const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+                                const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
+                                ++vg_rows;
+                                VgVec w; w.x = C.sig_v * n.x; w.y = C.sig_v * n.y;
+                                vg_tab[vg_wave][vg_rows][__lane_id()] = w;
+                                if ((int)__lane_id() == L) vg_ptr = &vg_tab[vg_wave][vg_rows][0];
+                                vg_uncovered &= ~(1ull << L);
+                            }
+                        }
+                    }
+                    if (vg_on) {
+                        const VgVec r = vg_ptr[cyc];
+                        vn.x = v.x + r.x; vn.y = v.y + r.y;  // (lanes without a row of their own read zeros: they cannot clamp)
+                    } else {
+                        vn = noisy<RT, true>(v, C.sig_v, key, S * (uint32_t)cyc);
+                    }
+                }
             }
             if constexpr (JERK) {  // PL:437-440
                 R2<RT> vnext;
