@@ -1,6 +1,7 @@
 // gpr_api.hip -- the C ABI of libgpr_hip.so (include/gpr.h): handle management, ctor-time tables, launch plumbing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -162,6 +163,14 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
             ms = s0 > ms ? s0 : ms; mf = s1 > mf ? s1 : mf;
         }
     c.max_csum_step = (RT)ms; c.max_csum_safe = (RT)mf;
+    // box shape: the edges of two rectangles cannot cross while their bounding boxes are apart
+    double m0 = -1.0, m1 = -1.0;
+    for (int i = 0; i < g.num_movers - 1; ++i)
+        for (int j = i + 1; j < g.num_movers; ++j) {
+            m0 = std::max(m0, e.csize[(size_t)2 * i] + e.csize[(size_t)2 * j]);
+            m1 = std::max(m1, e.csize[(size_t)2 * i + 1] + e.csize[(size_t)2 * j + 1]);
+        }
+    c.max_b0sum = (RT)m0; c.max_b1sum = (RT)m1;
     // noise is bounded (gpr-rng-v1 draws the Box-Muller radius from 16 bits): |reading - truth| <= sigma * R per component.
     // The slack covers the rounding of the compared expressions (a few ulp of a coordinate of a few metres).
     const double slack = sizeof(RT) == 8 ? 1e-12 : 1e-5;
@@ -314,9 +323,12 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     P.noise = (c.std_noise[0] != 0.0) || (c.std_noise[1] != 0.0) || (c.std_noise[2] != 0.0);
     // "full layout" shortcut of the throughput-mode wall check: every cell holds a tile and every collision circle, with all
     // offsets added, is smaller than half a tile
-    bool full = n_tiles == c.num_tiles_x * c.num_tiles_y && c.c_shape == GPR_SHAPE_CIRCLE;
+    // (box shape: its circumradius; then every vertex stays within the neighbours of the centre's tile, a grid without holes has
+    // no missing-corner case (BE:657-783), and BE:459-788 reduces to "all four vertices strictly inside the grid")
+    bool full = n_tiles == c.num_tiles_x * c.num_tiles_y;
     for (int i = 0; i < c.num_movers; ++i) {
-        const double cs = c.c_size[2 * i] + c.c_offset_wall + c.c_offset;
+        const double o = c.c_offset_wall + c.c_offset;
+        const double cs = c.c_shape == GPR_SHAPE_CIRCLE ? c.c_size[2 * i] + o : std::hypot(c.c_size[2 * i] + o, c.c_size[2 * i + 1] + o);
         full = full && cs < c.tile_half_size[0] && cs < c.tile_half_size[1];
     }
     P.layout_full = full;

@@ -27,6 +27,7 @@ template <typename RT> struct Cst {
     RT min_x, min_y, max_x, max_y, min_goal_dist, reward_success;
     RT c_offset, c_offset_wall, tile_hx, tile_hy;
     RT max_csum_step, max_csum_safe;  // max over mover pairs of (c_i + c_j), without / with the safety offset (BE:390,409)
+    RT max_b0sum, max_b1sum;          // box shape: max over mover pairs of the summed half sizes, per axis (no offset)
     RT gx0, gx1, gy0, gy1;            // outer edges of the tile grid: lo of the first tile, hi of the last tile, per axis
     RT band_p, band_v;                // how far a noisy position / velocity reading can be from the true one (+ rounding slack)
     RT step1;                         // upper bound of |p(cycle k+1) - p(cycle k)| of one mover: dt (v_max + band_v), with rounding slack
@@ -590,12 +591,36 @@ template <typename RT, int LPE, int D> struct BoxSweep {
             near |= dist <= lim + extra;
             const bool pre = dist <= lim;
             if (with_rects && (__ballot(pre) != 0ull)) {                        // rectangles only when some lane needs them
-                RT ox[4], oy[4];
+                // edges of two rectangles can only cross (GEO:107-138, 1e-7 tolerances) where their bounding boxes overlap: the
+                // 16 segment-pair tests run only if some lane's pair gets that far
+                const RT lox = fmin(fmin(vx[0], vx[1]), fmin(vx[2], vx[3])), hix = fmax(fmax(vx[0], vx[1]), fmax(vx[2], vx[3]));
+                const RT loy = fmin(fmin(vy[0], vy[1]), fmin(vy[2], vy[3])), hiy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
+                const RT slack = (RT)1e-6;
+                const bool boxes = pre & (lox <= rot<LPE, D>(hix) + slack) & (rot<LPE, D>(lox) <= hix + slack) &
+                                   (loy <= rot<LPE, D>(hiy) + slack) & (rot<LPE, D>(loy) <= hiy + slack);
+                if (__ballot(boxes) != 0ull) {
+                    RT ox[4], oy[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ox[r] = rot<LPE, D>(vx[r]); oy[r] = rot<LPE, D>(vy[r]); }
-                hit |= pre & rects_intersect_v<RT>(vx, vy, ox, oy);            // BE:417-422
+                    for (int r = 0; r < 4; ++r) { ox[r] = rot<LPE, D>(vx[r]); oy[r] = rot<LPE, D>(vy[r]); }
+                    hit |= boxes & rects_intersect_v<RT>(vx, vy, ox, oy);      // BE:417-422
+                }
             }
             BoxSweep<RT, LPE, D + 1>::run(vx, vy, x, y, cmax, extra, with_rects, hit, near);
+        }
+    }
+};
+// box shape, noise-free (axis-aligned) rectangles: is some partner's bounding box, both inflated, within reach? |dx| <= sx and
+// |dy| <= sy with sx, sy = summed half sizes + what two noisy reads can add. Conservative for any noisy read of both poses.
+template <typename RT, int LPE, int D> struct BoxNear {
+    static __device__ __forceinline__ bool run(RT x, RT y, RT sx, RT sy) {
+        if constexpr (LPE == 1) {
+            return false;
+        } else {
+            RT dx, dy;
+            rot_diff2<LPE, D>(x, y, dx, dy);
+            const bool n = (absr(dx) <= sx) & (absr(dy) <= sy);
+            if constexpr (D < LPE / 2) return n | BoxNear<RT, LPE, D + 1>::run(x, y, sx, sy);
+            else return n;
         }
     }
 };

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
     const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
-    if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
+    if constexpr (!FULL || SHAPE == 1) stage_tables(lds, P.tables, P.table_bytes);  // (the box functions read the tables)
     else __syncthreads();  // (reset_count is initialised)
     const Tables<RT> T = make_tables<RT>(lds, P);
     const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);  // BE:487, add_safety_offset=False
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const RT pair_band = Math<RT>::literal ? band_pair : (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
     const RT pair_near2 = (C.max_csum_step + band_pair) * (C.max_csum_step + band_pair) * (RT)1.000001;  // squared, with the noise band
 
-    if constexpr (!Math<RT>::literal && SHAPE == 0) {
+    if constexpr (!Math<RT>::literal && (SHAPE == 0 || FULL)) {
     // ---------------------------------------------------------------------------------------------------------------
     // Throughput loop: float arithmetic, circle shape, acceleration actions. Same decisions as the generic loop below.
     //
@@ -345,10 +345,20 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     constexpr int KC1 = 3, KC2 = 10, KC3 = 40;
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
-    RT wx_l = cw_step.wx;                                  // wall: valid iff reach < wx_l (full grid)
-    RT w0 = every ? -INF : wx_l - C.band_p;                 // certainly valid, whatever the noise, iff reach < w0
-    const RT wband = every ? INF : C.band_p;
+    // Box shape on a grid without holes: noise-free the rectangle is axis-aligned (identity quaternion), so its wall test is the
+    // circle's with per-axis sizes, "close to a wall" allows for the vertex displacement band_b of a noisy read, and "close to
+    // another mover" means centres within the summed circumradii (+ 2 band_b); the exact rectangle tests (BE:559-783,
+    // GEO:107-138: 16 segment pairs per rectangle pair) run only in the cycles in which something is that close.
+    const CircleSize<RT> cw_thr = SHAPE == 0 ? cw_step
+        : CircleSize<RT>{bw0, (RT)0, (RT)0, (RT)0.5 * (C.gx1 - C.gx0) - bw0, (RT)0.5 * (C.gy1 - C.gy0) - bw1};
+    const RT band_w = SHAPE == 0 ? C.band_p : band_b;
+    RT wx_l = cw_thr.wx;                                   // wall: valid iff reach < wx_l (full grid)
+    RT w0 = every ? -INF : wx_l - band_w;                   // certainly valid, whatever the noise, iff reach < w0
+    const RT wband = every ? INF : band_w;
     const RT pb = C.max_csum_step + band_pair;
+    // box shape: "close to another mover" = the bounding boxes of the two (noise-free: axis-aligned) rectangles, each inflated
+    // by the vertex displacement of a noisy read, overlap
+    RT bnx = every ? INF : C.max_b0sum + (RT)2 * band_b + (RT)2e-6, bny = every ? INF : C.max_b1sum + (RT)2 * band_b + (RT)2e-6;
     RT pthr_l = pair_thr;                                  // pair: hit iff d2 <= pthr_l
     RT p0r = every ? INF : pb * pb * (RT)1.00001;          // certainly no hit, whatever the noise, iff d2 > p0r
     const RT pband = every ? INF : pair_band;
@@ -363,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const RT adt = Math<RT>::sqrt_(dtl.x * dtl.x + dtl.y * dtl.y) * (RT)1.00001 + (RT)1e-7;
     auto rung = [&](int k) { const RT m = vlim_c * (RT)0.99999 - (RT)k * adt; return m > (RT)0 ? m * m : (RT)-1; };
     RT c1r = rung(KC1), c2r = rung(KC2), c3r = rung(KC3);
-#define GPR_LANE_OUT() do { wx_l = w0 = INF; pthr_l = p0r = (RT)-1; c1r = c2r = c3r = INF; if (!every) vneed2_l = INF; } while (0)
+#define GPR_LANE_OUT() do { wx_l = w0 = INF; pthr_l = p0r = bnx = bny = (RT)-1; c1r = c2r = c3r = INF; if (!every) vneed2_l = INF; } while (0)
     if (!live) GPR_LANE_OUT();
     if (lane_of(frozen_m)) { dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT(); }
     // index of a noise draw of this cycle, formed in scalar registers where it is needed (kept out of the loop's induction
@@ -449,7 +459,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         unsigned long long sp_w, sp_p = 0ull;
         bool w_valid = true, w_unc = false;
         if constexpr (FULL) {
-            e = wall_reach_centred<RT>(q.x, q.y, cw_step);
+            e = wall_reach_centred<RT>(q.x, q.y, cw_thr);
             sp_w = __ballot(!(e < w0));
         } else {
             p.x = p0.x + dp.x; p.y = p0.y + dp.y;
@@ -457,14 +467,40 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             sp_w = every ? ~0ull : (__ballot(!w_valid | w_unc) & live_m & ~frozen_m);
         }
         if constexpr (LPE > 1) {
-            md = pair_min_dist<RT, LPE>(q.x, q.y);
-            sp_p = __ballot(md <= p0r);
+            if constexpr (SHAPE == 0) {
+                md = pair_min_dist<RT, LPE>(q.x, q.y);
+                sp_p = __ballot(md <= p0r);
+            } else {
+                sp_p = __ballot(BoxNear<RT, LPE, 1>::run(q.x, q.y, bnx, bny));
+            }
         }
         if ((sp_w | sp_p) == 0ull) continue;
         GPR_WT(++wt_near;)
         p.x = p0.x + dp.x; p.y = p0.y + dp.y;
         // ---- something is close: the exact checks, each on its own noisy position read ----
         unsigned long long wraw, hraw = 0ull;
+        if constexpr (SHAPE == 1) {  // the generic loop's box checks, verbatim
+            const unsigned long long act = live_m & ~frozen_m;
+            const Pose<RT> qb{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0};
+            if constexpr (NOISE) {
+                bool unc;
+                wraw = __ballot(!pos_valid_box<RT, true>(T, P, qb, bw0, bw1, band_b, &unc));
+                if (every | ((__ballot(unc) & act) != 0ull)) {
+                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u));
+                    wraw = __ballot(!pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr));
+                }
+                bool near;
+                (void)box_pair_hit<RT, LPE>(qb, c, c1, (RT)2 * band_b, false, &near);
+                if (every | ((__ballot(near) & act) != 0ull)) {
+                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u + R));
+                    hraw = __ballot(box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr));
+                }
+            } else {
+                wraw = __ballot(!pos_valid_box<RT, false>(T, P, qb, bw0, bw1, (RT)0, nullptr));
+                hraw = __ballot(box_pair_hit<RT, LPE>(qb, c, c1, (RT)0, true, nullptr));
+            }
+            wraw &= act; hraw &= act;
+        } else {
         if constexpr (FULL) {
             wraw = __ballot(!(e < wx_l));
             if constexpr (NOISE) {
@@ -491,6 +527,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                     hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
                 }
             }
+        }
         }
         // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle
         if ((wraw | hraw) != 0ull) {
@@ -803,7 +840,7 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc], c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];
     R2<RT> p = load2<ST, RT>(P.pos, idx), g = load2<ST, RT>(P.goal, idx);
     if (mv >= M) p.x = p.y = far_away<RT>();
-    if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
+    if constexpr (!FULL || SHAPE == 1) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
     Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, p, g, wc, mc);
@@ -825,7 +862,7 @@ template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, i
 static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) {
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
-    const unsigned lds = FULL ? 0u : P.table_bytes;
+    const unsigned lds = (FULL && SHAPE == 0) ? 0u : P.table_bytes;
     if (is_reset) {
         hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     } else {
@@ -834,7 +871,12 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     return hipGetLastError();
 }
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipError_t launch_one(bool is_reset, const KParams &P, hipStream_t s) {
-    if (P.c_shape != 0) return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 1>(is_reset, P, s);  // 'box' collision shape
+    if (P.c_shape != 0) {  // 'box' collision shape; grids without holes have a fast wall test here too (see gpr_create)
+        if constexpr (!Math<RT>::literal) {
+            if (P.layout_full) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 1>(is_reset, P, s);
+        }
+        return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 1>(is_reset, P, s);
+    }
     // the throughput-mode wall check has a table-free form for grids without holes (pos_valid_circle): separate kernels
     if constexpr (!Math<RT>::literal) {
         if (P.layout_full) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 0>(is_reset, P, s);

@@ -388,6 +388,7 @@ def test_lazy_noise_is_exact(gpr, monkeypatch):
     box = {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.001}
     for layout, M, prec, cp, ncyc in ((np.ones((6, 6)), 4, 'f32', None, 40), (HOLES, 3, 'f32', None, 40), (np.ones((5, 5)), 2, 'f64', None, 40),
                                       (np.ones((4, 6)), 2, 'f32', None, 40), (HOLES, 4, 'f32', box, 40), (np.ones((4, 4)), 3, 'f64', box, 40),
+                                      (np.ones((6, 6)), 4, 'f32', box, 40),     # box shape on a grid without holes: fast wall / pair pre-tests
                                       (np.ones((6, 6)), 4, 'f32', None, 100),   # more cycles than an LDS row of readings holds
                                       (np.ones((8, 8)), 1, 'f32', None, 40),    # one mover: no pair check at all
                                       (np.ones((10, 10)), 16, 'f32', None, 7)):  # 16 lanes per env, odd cycle count
