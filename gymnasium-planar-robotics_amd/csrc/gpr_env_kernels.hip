@@ -64,6 +64,9 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);  // BE:487 with add_safety_offset=True
     const RT ws0 = (c + C.c_offset_wall) + C.c_offset, ws1 = (c1 + C.c_offset_wall) + C.c_offset;  // box: wall sizes, BE:487
     const RT ps0 = c + C.c_offset, ps1 = c1 + C.c_offset;                                        // box: pair sizes with offset, BE:390
+    // box shape on a grid without holes (FULL): a candidate has the identity quaternion, its rectangle is axis-aligned, and
+    // BE:459-788 is "the rectangle lies strictly inside the grid" -- the circle's table-free test with per-axis sizes
+    const CircleSize<RT> cw_box_safe{ws0, (RT)0, (RT)0, (RT)0.5 * (C.gx1 - C.gx0) - ws0, (RT)0.5 * (C.gy1 - C.gy0) - ws1};
     constexpr uint32_t R = SHAPE == 0 ? 1u : 3u;  // normal pairs per noisy qpos read
     const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, (uint32_t)mvc);
     const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
@@ -84,7 +87,8 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.max_csum_safe);       // PL:381-383
         } else {
             const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
-            w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
+            if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
+            else w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
             hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
         }
         bool bad = group_any<LPE>(w | hit);
@@ -103,6 +107,8 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         bool w;  // PL:403-404
         if constexpr (SHAPE == 0) {
             w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);
+        } else if constexpr (FULL) {
+            w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);
         } else {
             w = live & !pos_valid_box<RT, false>(T, P, Pose<RT>{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0}, ws0, ws1, (RT)0, nullptr);
         }

@@ -16,3 +16,5 @@ box={'shape':'box','size':np.array([0.0775,0.0775]),'offset':0.0}
 run(65536,4,6,box); run(65536,4,6,box,sigma=0.0); run(4096,4,6,box)
 holes=np.ones((6,6)); 
 run(65536,1,6,box,sigma=0.0); run(65536,2,6,box,sigma=0.0); run(65536,4,6,box,sigma=0.0, num_cycles=0)
+run(65536,4,6,box,sigma=0.0, autoreset_mode='disabled', max_episode_steps=None)
+run(65536,4,6,box,sigma=0.0, num_cycles=10)
