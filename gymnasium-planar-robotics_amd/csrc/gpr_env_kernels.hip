@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         // BE:1888-1901, noise-free and with the noise bands added: can anything at all have happened?
         RT e = (RT)0, md = INF;
         unsigned long long sp_w, sp_p = 0ull;
-        bool w_valid = true, w_unc = false;
+        bool w_valid = true, w_unc = false, near_b = false;
         if constexpr (FULL) {
             e = wall_reach_centred<RT>(q.x, q.y, cw_thr);
             sp_w = __ballot(!(e < w0));
@@ -477,7 +477,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 md = pair_min_dist<RT, LPE>(q.x, q.y);
                 sp_p = __ballot(md <= p0r);
             } else {
-                sp_p = __ballot(BoxNear<RT, LPE, 1>::run(q.x, q.y, bnx, bny));
+                near_b = BoxNear<RT, LPE, 1>::run(q.x, q.y, bnx, bny);
+                sp_p = __ballot(near_b);
             }
         }
         if ((sp_w | sp_p) == 0ull) continue;
@@ -485,25 +486,22 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         p.x = p0.x + dp.x; p.y = p0.y + dp.y;
         // ---- something is close: the exact checks, each on its own noisy position read ----
         unsigned long long wraw, hraw = 0ull;
-        if constexpr (SHAPE == 1) {  // the generic loop's box checks, verbatim
+        if constexpr (SHAPE == 1) {
+            // the exact rectangle tests (BE:559-783, GEO:107-138) on noisy reads, for the lanes that can need them: the noise-free
+            // (axis-aligned) verdicts stand wherever no read within the noise bound could change them
             const unsigned long long act = live_m & ~frozen_m;
-            const Pose<RT> qb{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0};
+            wraw = __ballot(!(e < wx_l));
             if constexpr (NOISE) {
-                bool unc;
-                wraw = __ballot(!pos_valid_box<RT, true>(T, P, qb, bw0, bw1, band_b, &unc));
-                if (every | ((__ballot(unc) & act) != 0ull)) {
+                if (every | ((__ballot(!(__builtin_fabsf(wx_l - e) > wband)) & act) != 0ull)) {
                     const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u));
                     wraw = __ballot(!pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr));
                 }
-                bool near;
-                (void)box_pair_hit<RT, LPE>(qb, c, c1, (RT)2 * band_b, false, &near);
-                if (every | ((__ballot(near) & act) != 0ull)) {
+                if (every | ((__ballot(near_b) & act) != 0ull)) {
                     const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u + R));
                     hraw = __ballot(box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr));
                 }
             } else {
-                wraw = __ballot(!pos_valid_box<RT, false>(T, P, qb, bw0, bw1, (RT)0, nullptr));
-                hraw = __ballot(box_pair_hit<RT, LPE>(qb, c, c1, (RT)0, true, nullptr));
+                if ((__ballot(near_b) & act) != 0ull) hraw = __ballot(box_pair_hit<RT, LPE>(Pose<RT>{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0}, c, c1, (RT)0, true, nullptr));
             }
             wraw &= act; hraw &= act;
         } else {

@@ -5,7 +5,8 @@ sys.path.insert(0, '.')
 import gymnasium_planar_robotics_amd as gpr
 E, M = 65536, 4
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-5
-env = gpr.VecBenchmarkPlanningEnv(np.ones((6, 6)), M, num_envs=E, std_noise=sigma)
+cp = {'shape': 'box', 'size': np.array([0.0775, 0.0775])} if (len(sys.argv) > 2 and sys.argv[2] == 'box') else None
+env = gpr.VecBenchmarkPlanningEnv(np.ones((6, 6)), M, num_envs=E, std_noise=sigma, collision_params=cp)
 env.reset(seed=0)
 acts = [(torch.rand(E, 2 * M, device='cuda') * 20 - 10).to(env.dtype) for _ in range(8)]
 for i in range(150): env.step_into(acts[i % 8], env._out)
