@@ -125,10 +125,30 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, R);
         mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
     } else {
-        const Pose<RT> qw_ = noisy_pose<RT, NOISE>(p, C.sig_p, kn, 0u);
-        wc = group_any<LPE>(live & !pos_valid_box<RT, false>(T, P, qw_, ws0, ws1, (RT)0, nullptr));
-        const Pose<RT> qp = noisy_pose<RT, NOISE>(p, C.sig_p, kn, R);
-        mc = group_any<LPE>(live & box_pair_hit<RT, LPE>(qp, c + C.c_offset * (RT)0, c1 + C.c_offset * (RT)0, (RT)0, true, nullptr));
+        bool lazy_done = false;
+        if constexpr (FULL) {
+            // grid without holes, throughput mode: the accepted start is axis-aligned and (almost always) further from the walls
+            // and from the other movers than a noisy read can bridge: then the two noisy checks are decided without their reads
+            // (six normal pairs, rotated vertices, the table walk, 16 segment pairs); exact, as in the step loop
+            if (P.eager_noise == 0) {
+                const RT bdiag = Math<RT>::sqrt_(ws0 * ws0 + ws1 * ws1);
+                const RT band_b = C.band_p * ((RT)1 + (RT)3.5 * bdiag) + (RT)1e-6 * bdiag;
+                const RT e = wall_reach_full<RT>(C, p.x, p.y, cw_box_safe);
+                const bool w_unc = live & !(__builtin_fabsf(cw_box_safe.wx - e) > band_b);
+                const bool near_b = live & BoxNear<RT, LPE, 1>::run(p.x, p.y, C.max_b0sum + (RT)2 * band_b + (RT)2e-6, C.max_b1sum + (RT)2 * band_b + (RT)2e-6);
+                if (__ballot(w_unc | near_b) == 0ull) {
+                    wc = group_any<LPE>(live & !(e < cw_box_safe.wx));
+                    mc = false;
+                    lazy_done = true;
+                }
+            }
+        }
+        if (!lazy_done) {
+            const Pose<RT> qw_ = noisy_pose<RT, NOISE>(p, C.sig_p, kn, 0u);
+            wc = group_any<LPE>(live & !pos_valid_box<RT, false>(T, P, qw_, ws0, ws1, (RT)0, nullptr));
+            const Pose<RT> qp = noisy_pose<RT, NOISE>(p, C.sig_p, kn, R);
+            mc = group_any<LPE>(live & box_pair_hit<RT, LPE>(qp, c + C.c_offset * (RT)0, c1 + C.c_offset * (RT)0, (RT)0, true, nullptr));
+        }
     }
     return observe<ST, RT, LPE, NOISE>(P, kn, 2u * R, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
 }
