@@ -1,38 +1,47 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the vectorised BenchmarkPlanningEnv, 4 movers @ 65 536 envs per MI355X.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 100
+    python bench.py --gpus N --steps K --warmup W            # N > 1 without a launcher: this process spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one env-step of every env of every rank: ONE fused HIP kernel launch per rank per step (clip -> 40 control
 cycles of clamp / integrate / wall check / pair sweep -> observation, reward, done flags -> same-step auto-reset), i.e. what
 `VecBenchmarkPlanningEnv.step()` does, with the outputs written straight into a [T = 50, E, .] rollout buffer. Inputs
-(a ring of pre-generated random actions) are resident in HBM before the timed region. For N > 1 the env batch is sharded
-(weak scaling: 65 536 envs per GPU, one process per GPU); step() has no exchange step, so the timed region of `value` holds
-no collective (barrier + synchronize on both sides, max over ranks). The one collective the design has -- ONE RCCL
-all-gather of the whole rollout buffer at a flush, every 50 steps -- is timed in a second pass of the same run and reported
-under config.rollout_gather: at this engine's rate a rank produces ~134 B x 2.9e9 env-steps/s = 390 GB/s of rollout data, and
-gathering eight such streams into every GPU is bound by xGMI, not by the env engine. Rank 0 prints one JSON line.
+(a ring of pre-generated random actions) are resident in HBM before the timed region. Episode phases are desynchronised
+before the warm-up (elapsed-step counters drawn uniformly from [0, 50)), so that even a short timed window sees the
+steady-state TimeLimit rate instead of a burst every 50 steps.
+
+Timed region: exactly K steps per block, R back-to-back blocks with R chosen (identically on every rank) so that the
+region lasts at least --min-seconds (0.1 s); barrier + synchronize on both sides, max over ranks. `value` = envs of all
+ranks x K x R / that time.
+
+For N > 1 the env batch is sharded (one process per GPU, contiguous env ranges, random streams keyed by global env id).
+`value` is WEAK scaling (65 536 envs per GPU); BASELINE.json's STRONG shape (65 536 envs in total) is timed in the same run and
+reported under config.strong_scaling. step() has no exchange step, so no timed region of an env-step rate holds a
+collective. Rollouts stay sharded (every rank's learner consumes its own [T, E/N, .] buffer); what crosses xGMI at a
+flush is ONE all_reduce of the six episode counters (48 bytes), timed as config.rollout_flush. Rank 0 prints one JSON line.
 
 Workload (BASELINE.json): BenchmarkPlanningEnv, 4 movers, layout ones(6,6), reference defaults
 (num_cycles 40, dt 1e-3, v_max 2, a_max 10, circle r 0.11, std_noise 1e-5, TimeLimit 50), actions ~ U(-a_max, a_max).
-The sigma = 0 variant is timed too and reported in `config` (extras), never as `value`.
+Extras in `config` (never `value`): sigma = 0; larger batches (262 144 and 1 048 576 envs); the reference's dtype
+(f64 and f32 storage / f64 arithmetic).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+T_ROLLOUT = 50
 
 
 def algorithmic_bytes_per_env_step(num_movers: int) -> int:
@@ -42,82 +51,158 @@ def algorithmic_bytes_per_env_step(num_movers: int) -> int:
 
 
 def measured_traffic(num_envs: int, num_movers: int):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/round1_hbm_traffic.json: FETCH_SIZE
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/round*_hbm_traffic.json: FETCH_SIZE
     and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read
     from inside this process; None when the profiled configuration is not the one being run."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'round1_hbm_traffic.json')) as f:
-            d = json.load(f)
-        if d['envs'] == num_envs and d['movers'] == num_movers:
-            return d['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ('round2_hbm_traffic.json', 'round1_hbm_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                d = json.load(f)
+            if d['envs'] == num_envs and d['movers'] == num_movers:
+                return d['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
-def run_gpu(args, rank, local_rank, world, std_noise, gather=False):
-    import torch.distributed as dist
+# ----------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it. Runs BEFORE anything touches the GPU (and never
+# re-execs): N child processes, one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is passed through.
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out or '').splitlines() if ln.startswith('{')]
+    if lines:
+        print(lines[-1], flush=True)
+    return max(abs(rc) for rc in rcs) if any(rcs) else (0 if lines else 1)
 
-    import gymnasium_planar_robotics_amd as gpr
 
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
-    M, E, T = args.movers, args.envs_per_gpu, 50
-    env = gpr.VecBenchmarkPlanningEnv(np.ones((args.tiles, args.tiles)), M, num_envs=E, device=device, std_noise=std_noise,
-                                      precision=args.precision, env_id_offset=rank * E)
-    buf = gpr.distributed.RolloutBuffer(T, E, M, env.obs_dim, dtype=env.dtype, device=device)
-    outs = []
-    for t in range(T):
-        s = buf.slot(t)
-        outs.append(env.bind_outputs(s['observation'], s['achieved_goal'], s['desired_goal'], s['reward'], s['terminated'], s['truncated']))
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    ring = (torch.rand(T, E, 2 * M, device=device, generator=gen, dtype=torch.float32) * (2 * env.a_max) - env.a_max).to(env.dtype)
-    buf['action'].copy_(ring)  # the rollout buffer's action field doubles as the action ring
-    actions = [buf['action'][t] for t in range(T)]
-    env.reset(seed=0)
+# ----------------------------------------------------------------------------------------------------------------------
+class Pass:
+    """One timed configuration on this rank."""
 
-    def do_steps(n, t0):
-        t = t0
+    def __init__(self, args, rank, local_rank, world, *, envs, std_noise=1e-5, precision=None, movers=None, tiles=None, flush=None):
+        import numpy as np
+        import torch
+
+        import gymnasium_planar_robotics_amd as gpr
+
+        self.args, self.rank, self.world = args, rank, world
+        self.device = torch.device('cuda', local_rank)
+        torch.cuda.set_device(self.device)
+        self.M, self.E = movers or args.movers, envs
+        tiles = tiles or args.tiles
+        precision = precision or args.precision
+        self.env = gpr.VecBenchmarkPlanningEnv(np.ones((tiles, tiles)), self.M, num_envs=envs, device=self.device, std_noise=std_noise,
+                                               precision=precision, env_id_offset=rank * envs)
+        env, M, E, T = self.env, self.M, self.E, T_ROLLOUT
+        self.buf = gpr.distributed.RolloutBuffer(T, E, M, env.obs_dim, dtype=env.dtype, device=self.device)
+        self.outs = []
+        for t in range(T):
+            s = self.buf.slot(t)
+            self.outs.append(env.bind_outputs(s['observation'], s['achieved_goal'], s['desired_goal'], s['reward'], s['terminated'], s['truncated']))
+        gen = torch.Generator(device=self.device).manual_seed(1234 + rank)
+        ring = (torch.rand(T, E, 2 * M, device=self.device, generator=gen, dtype=torch.float32) * (2 * env.a_max) - env.a_max).to(env.dtype)
+        self.buf['action'].copy_(ring)  # the rollout buffer's action field doubles as the action ring
+        self.actions = [self.buf['action'][t] for t in range(T)]
+        env.reset(seed=0)
+        # desynchronise the episode phases (TimeLimit counters), as a long-running job would be
+        env.elapsed_steps.copy_(torch.randint(0, T, (E,), device=self.device, generator=gen, dtype=torch.int32))
+        self.flush = flush
+        self.t = 0
+        self.slots_written = 0
+
+    def do_steps(self, n):
+        env, acts, outs = self.env, self.actions, self.outs
+        t = self.t
         for _ in range(n):
-            env.step_into(actions[t], outs[t])
+            env.step_into(acts[t], outs[t])
             t += 1
-            if t == T:
-                if gather:
-                    buf.flush()  # single RCCL all-gather of the rank's whole rollout buffer
+            if t == T_ROLLOUT:
+                if self.flush is not None:
+                    self.flush(self)
                 t = 0
-        return t
+        self.t = t
+        self.slots_written = min(T_ROLLOUT, self.slots_written + n)
 
-    def sync():
-        torch.cuda.synchronize(device)
-        if world > 1:
+    def sync(self):
+        import torch
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            import torch.distributed as dist
             dist.barrier()
-            torch.cuda.synchronize(device)
+            torch.cuda.synchronize(self.device)
 
-    with torch.cuda.device(device):
-        t_pos = do_steps(args.warmup, 0)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        sync()
-        ev0.record()  # on the stream the kernels are launched on (torch's current stream is what step_into passes down)
-        t0 = time.perf_counter()
-        do_steps(args.steps, t_pos)
-        ev1.record()
-        sync()
-        wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        w = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
-    done_frac = float((buf['terminated'].float().mean() + buf['truncated'].float().mean()).item())
-    nbytes = buf.nbytes
-    env.close()
-    del buf
-    torch.cuda.empty_cache()
-    return wall, gpu_ms, done_frac, nbytes
+    def run(self, steps, warmup, min_seconds):
+        """-> (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region, R)"""
+        import torch
+        with torch.cuda.device(self.device):
+            # pilot: the warm-up steps are timed (host clock) to size R
+            self.sync()
+            t0 = time.perf_counter()
+            self.do_steps(max(1, warmup))
+            self.sync()
+            est = (time.perf_counter() - t0) / max(1, warmup)
+            reps = max(1, int(math.ceil(min_seconds / max(1e-9, est * steps))))
+            if self.world > 1:
+                import torch.distributed as dist
+                r = torch.tensor([reps], device=self.device, dtype=torch.int64)
+                dist.all_reduce(r, op=dist.ReduceOp.MAX)
+                reps = int(r.item())
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.sync()
+            ev0.record()  # on the stream the kernels are launched on (torch's current stream is what step_into passes down)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.do_steps(steps)
+            ev1.record()
+            self.sync()
+            wall = time.perf_counter() - t0
+        gpu_ms = ev0.elapsed_time(ev1)
+        if self.world > 1:
+            import torch.distributed as dist
+            w = torch.tensor([wall], device=self.device, dtype=torch.float64)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w.item())
+        return wall, gpu_ms, reps
+
+    def done_fraction(self):
+        """mean over the rollout slots that were actually written of (terminated | truncated)"""
+        n = max(1, self.slots_written)
+        term, trunc = self.buf['terminated'][:n], self.buf['truncated'][:n]
+        return float(((term | trunc) != 0).float().mean().item())
+
+    def close(self):
+        import torch
+        self.env.close()
+        del self.buf, self.outs, self.actions
+        torch.cuda.empty_cache()
+
+
+def timed(args, rank, local_rank, world, steps=None, warmup=None, **kw):
+    p = Pass(args, rank, local_rank, world, **kw)
+    wall, gpu_ms, reps = p.run(steps or args.steps, args.warmup if warmup is None else warmup, args.min_seconds)
+    n = (steps or args.steps) * reps
+    res = {'wall': wall, 'gpu_ms': gpu_ms, 'reps': reps, 'n_steps': n, 'kernel_us': gpu_ms * 1e3 / n,
+           'env_steps_per_s': world * p.E * n / wall, 'done_fraction': p.done_fraction(), 'rollout_bytes': p.buf.nbytes}
+    p.close()
+    return res
 
 
 def cpu_baseline(args):
     """The oracle (plain-C port of the reference semantics, fp64) on this box's host cores: a bounded sample of the same workload."""
+    import numpy as np
+
     from oracle import oracle
 
     cores = os.cpu_count() or 1
@@ -146,67 +231,106 @@ def main():
     ap.add_argument('--movers', type=int, default=4)
     ap.add_argument('--tiles', type=int, default=6)
     ap.add_argument('--precision', default='f32', choices=['f32', 'f32_f64acc', 'f64'])
+    ap.add_argument('--min-seconds', type=float, default=0.1, help='minimum length of every timed region (blocks of --steps are repeated)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-rollout-gather', action='store_true', help='skip the extra pass that times the rollout all-gather (N > 1)')
-    ap.add_argument('--gather-timeout', type=float, default=240.0, help='seconds the rollout all-gather pass may take (N > 1)')
+    ap.add_argument('--no-extras', action='store_true', help='headline pass only (profiling runs)')
+    ap.add_argument('--rollout-gather', action='store_true', help='also time a full all-gather of the rollout buffers at every flush (N > 1)')
+    ap.add_argument('--gather-timeout', type=float, default=240.0, help='seconds the optional rollout all-gather pass may take')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' + --single-device rehearses N > 1 on one GPU")
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))  # nothing has touched the GPU in this process
 
     import gymnasium_planar_robotics_amd as gpr
 
     if args.single_device:
         os.environ['LOCAL_RANK'] = '0'
     rank, local_rank, world = gpr.distributed.init_from_env(args.backend)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
-
-    wall, gpu_ms, done_frac, nbytes = run_gpu(args, rank, local_rank, world, 1e-5)  # headline: the reference's default noise
-    wall0, gpu_ms0, _, _ = run_gpu(args, rank, local_rank, world, 0.0)              # extra: sigma = 0
+    if world != args.gpus and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running on {world} ranks', file=sys.stderr)
 
     E, M, K = args.envs_per_gpu, args.movers, args.steps
-    kernel_s = gpu_ms * 1e-3 / K  # HIP events around the timed region / launches: average duration of the step kernel
+    head = timed(args, rank, local_rank, world, envs=E)                    # headline: the reference's default noise
     B = algorithmic_bytes_per_env_step(M)
+    kernel_s = head['kernel_us'] * 1e-6  # HIP events around the timed region / launches: average duration of the step kernel
     achieved = B * E / kernel_s / 1e9
+    cfg = {
+        'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
+                    'std_noise 1e-5 (reference default), TimeLimit 50 with desynchronised episode phases, same-step auto-reset, '
+                    'actions ~ U(-10, 10)',
+        'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
+        'timed_steps': head['n_steps'], 'timed_blocks': head['reps'], 'timed_seconds': head['wall'],
+        'done_fraction_per_step': head['done_fraction'],
+    }
     line = {
         'metric': 'env-steps/sec, BenchmarkPlanningEnv 4 movers @ 65536 envs per MI355X',
-        'value': world * E * K / wall, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
-        'ms_per_step': wall / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'value': head['env_steps_per_s'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+        'ms_per_step': head['wall'] / head['n_steps'] * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'f32': 'f32', 'f32_f64acc': 'f32 storage / f64 arithmetic', 'f64': 'f64'}[args.precision], 'data': 'synthetic',
-        'config': {
-            'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
-                        'std_noise 1e-5 (reference default), TimeLimit 50, same-step auto-reset, actions ~ U(-10, 10)',
-            'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
-            'done_fraction_per_step': done_frac,
-            'sigma0_env_steps_per_s': world * E * K / wall0, 'sigma0_kernel_us': gpu_ms0 * 1e3 / K,
-        },
+        'config': cfg,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>', 'kernel_us': kernel_s * 1e6,
-                     'algorithmic_bytes_per_env_step': B},
+                     'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>',
+                     'kernel_us': head['kernel_us'], 'algorithmic_bytes_per_env_step': B},
     }
 
-    if world > 1 and not args.no_rollout_gather:
-        # extra pass: + the rollout all-gather. It moves GBs per flush over xGMI; a watchdog makes sure that the line above is
-        # printed (without this extra) even if that collective should not complete.
+    if not args.no_extras:
+        s0 = timed(args, rank, local_rank, world, envs=E, std_noise=0.0)
+        cfg['sigma0_env_steps_per_s'] = s0['env_steps_per_s']
+        cfg['sigma0_kernel_us'] = s0['kernel_us']
+        if world > 1:
+            # BASELINE.json's strong-scaling shape: 65 536 envs in total
+            Es = max(1, args.envs_per_gpu // world)
+            st = timed(args, rank, local_rank, world, envs=Es)
+            cfg['strong_scaling'] = {'envs_total': Es * world, 'envs_per_gpu': Es, 'env_steps_per_s': st['env_steps_per_s'],
+                                     'ms_per_step': st['wall'] / st['n_steps'] * 1e3, 'kernel_us': st['kernel_us']}
+
+            def flush_counters(p):
+                p.env.all_reduce_episode_counters()  # ONE all_reduce of six uint64 counters; rollouts stay sharded
+
+            fl = timed(args, rank, local_rank, world, envs=E, flush=flush_counters)
+            cfg['rollout_flush'] = {
+                'what': 'rollouts stay sharded (each rank\'s learner reads its own [50, E, .] buffer); every 50 steps ONE all_reduce '
+                        'of the six on-device episode counters (48 B) inside the timed region',
+                'env_steps_per_s': fl['env_steps_per_s'], 'rollout_bytes_per_rank_per_flush': fl['rollout_bytes']}
+        else:
+            sizes = {}
+            for n in (4096, 262144, 1048576):
+                r = timed(args, rank, local_rank, world, envs=n, steps=max(50, K * E // max(n, E) // 2), warmup=min(args.warmup, 60))
+                sizes[str(n)] = {'env_steps_per_s': r['env_steps_per_s'], 'kernel_us': r['kernel_us'],
+                                 'hbm_frac': B * n / (r['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            cfg['other_batch_sizes'] = sizes
+            if args.precision == 'f32':
+                prec = {}
+                for pr in ('f32_f64acc', 'f64'):
+                    r = timed(args, rank, local_rank, world, envs=E, precision=pr, steps=max(50, K // 4), warmup=min(args.warmup, 60))
+                    bytes_pr = B if pr == 'f32_f64acc' else 2 * (72 * M) + 17
+                    prec[pr] = {'env_steps_per_s': r['env_steps_per_s'], 'kernel_us': r['kernel_us'],
+                                'hbm_frac': bytes_pr * E / (r['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                cfg['reference_dtype'] = prec
+
+    if world > 1 and args.rollout_gather:
+        # optional: + a full all-gather of every rank's rollout buffer per flush (GBs over xGMI; bound by the links, not by
+        # the env engine -- DESIGN.md section 4). A watchdog makes sure the headline is printed if the collective hangs, and
+        # that the hang is NOT reported as success.
         import threading
 
         def give_up():
             if rank == 0:
-                line['config']['rollout_gather'] = {'status': f'no result within {args.gather_timeout:.0f} s'}
+                cfg['rollout_gather'] = {'status': f'no result within {args.gather_timeout:.0f} s'}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(args.gather_timeout, give_up)
         dog.daemon = True
         dog.start()
-        wall_g = run_gpu(args, rank, local_rank, world, 1e-5, gather=True)[0]
+        g = timed(args, rank, local_rank, world, envs=E, flush=lambda p: p.buf.flush())
         dog.cancel()
-        flushes = max(1, (args.warmup % 50 + K) // 50)
-        line['config']['rollout_gather'] = {
-            'what': 'same run with ONE RCCL all_gather_into_tensor of every rank\'s [50, E, .] rollout buffer per 50 steps inside the timed region',
-            'env_steps_per_s': world * E * K / wall_g, 'bytes_per_rank_per_flush': nbytes,
-            'ms_per_flush': max(0.0, wall_g - wall) / flushes * 1e3,
-            'allgather_busbw_GBps': (world - 1) * nbytes / max(1e-9, (wall_g - wall) / flushes) / 1e9}
+        cfg['rollout_gather'] = {
+            'what': 'ONE all_gather_into_tensor of every rank\'s [50, E, .] rollout buffer per 50 steps inside the timed region',
+            'env_steps_per_s': g['env_steps_per_s'], 'bytes_per_rank_per_flush': g['rollout_bytes']}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -38,6 +38,9 @@ struct gpr_env {
     int lpe = 1;
     bool push_ready = false;
     size_t wave_timing_words = 0;
+    uint32_t *counters = nullptr;  // [waves][GPR_NUM_COUNTERS] per-wavefront episode counters (gpr_enable_counters)
+    size_t counter_rows = 0;
+    bool counters_on = false;
     PushCst<float> push_f{};
     PushCst<double> push_d{};
     PushPtrs push_ptrs{};
@@ -197,6 +200,7 @@ KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
     P.tick_lo = (uint32_t)e->tick; P.tick_hi = (uint32_t)(e->tick >> 32);
     P.pos = e->state.pos_dev; P.vel = e->state.vel_dev; P.acc = e->state.acc_dev; P.goal = e->state.goal_dev;
     P.elapsed = e->state.elapsed_dev;
+    P.counters = e->counters_on ? e->counters : nullptr;
     if (out) {
         P.obs = out->observation_dev; P.ag = out->achieved_goal_dev; P.dg = out->desired_goal_dev; P.reward = out->reward_dev;
         P.terminated = out->terminated_dev; P.truncated = out->truncated_dev; P.is_success = out->is_success_dev;
@@ -339,7 +343,7 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
 #ifdef GPR_WAVE_TIMING
     // debug build: per-wavefront clocks of the last step kernel, dumped to $GPR_WAVE_TIMING (a file name) by gpr_destroy
     if (std::getenv("GPR_WAVE_TIMING")) {
-        e->wave_timing_words = (size_t)((c.num_envs * e->lpe + 63) / 64) * 8;
+        e->wave_timing_words = (size_t)((c.num_envs * e->lpe + 63) / 64) * 16;
         if (hipMalloc(&P.wave_timing, e->wave_timing_words * 4) == hipSuccess) (void)hipMemset(P.wave_timing, 0, e->wave_timing_words * 4);
         else P.wave_timing = nullptr;
     }
@@ -360,6 +364,7 @@ void gpr_destroy(gpr_env *env) {
         (void)hipFree(env->base.wave_timing);
     }
 #endif
+    if (env->counters) (void)hipFree(env->counters);
     if (env->tab_f32.dev) (void)hipFree(env->tab_f32.dev);
     if (env->tab_f64.dev) (void)hipFree(env->tab_f64.dev);
     delete env;
@@ -379,6 +384,42 @@ int gpr_seed(gpr_env *env, uint64_t seed) {
     env->seed = seed;
     env->tick = 0;
     return GPR_OK;
+}
+
+int gpr_get_rng_state(const gpr_env *env, uint64_t *seed_out, uint64_t *tick_out) {
+    if (!env || !seed_out || !tick_out) return fail(nullptr, GPR_E_INVALID, "gpr_get_rng_state: NULL argument");
+    *seed_out = env->seed;
+    *tick_out = env->tick;
+    return GPR_OK;
+}
+
+int gpr_set_rng_state(gpr_env *env, uint64_t seed, uint64_t tick) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_set_rng_state: NULL handle");
+    env->seed = seed;
+    env->tick = tick;
+    return GPR_OK;
+}
+
+int gpr_enable_counters(gpr_env *env, int32_t enable) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_enable_counters: NULL handle");
+    if (enable && !env->counters) {
+        // one row per wavefront of the step kernel (planning: lpe lanes per env; pushing: one lane per env -- never more rows)
+        env->counter_rows = (size_t)((env->cfg.num_envs * env->lpe + 63) / 64);
+        const size_t bytes = env->counter_rows * GPR_NUM_COUNTERS * sizeof(uint32_t);
+        hipError_t he = hipMalloc(reinterpret_cast<void **>(&env->counters), bytes);
+        if (he != hipSuccess) { env->counters = nullptr; return fail_hip(env, he, "gpr_enable_counters: hipMalloc"); }
+        he = hipMemset(env->counters, 0, bytes);
+        if (he != hipSuccess) return fail_hip(env, he, "gpr_enable_counters: hipMemset");
+    }
+    env->counters_on = enable != 0;
+    return GPR_OK;
+}
+
+int gpr_read_counters(gpr_env *env, uint64_t *totals_dev, void *hip_stream) {
+    if (!env || !totals_dev) return fail(env, GPR_E_INVALID, "gpr_read_counters: NULL argument");
+    if (!env->counters) return fail(env, GPR_E_UNBOUND, "gpr_read_counters: call gpr_enable_counters first");
+    hipError_t he = launch_counter_reduce(env->counters, (int64_t)env->counter_rows, totals_dev, as_stream(hip_stream));
+    return he == hipSuccess ? GPR_OK : fail_hip(env, he, "counter reduce kernel launch");
 }
 
 int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {
@@ -419,16 +460,19 @@ int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, co
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "reward kernel launch");
 }
 
-int gpr_agent_views(gpr_env *env, const void *observation_dev, const void *achieved_goal_dev, const void *desired_goal_dev,
-                    const void *reward_dev, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream) {
+int gpr_agent_views(gpr_env *env, const gpr_step_out *out, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_agent_views: NULL handle");
-    if (!observation_dev || !achieved_goal_dev || !desired_goal_dev || !reward_dev || !agent_obs_dev || !agent_reward_dev)
-        return fail(env, GPR_E_INVALID, "gpr_agent_views: bad argument");
-    KParams P = make_params(env, nullptr, true);
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    if (!agent_obs_dev || !agent_reward_dev) return fail(env, GPR_E_INVALID, "gpr_agent_views: bad argument");
+    if (env->cfg.autoreset_mode == GPR_AUTORESET_SAME_STEP && !out->final_achieved_goal_dev)
+        return fail(env, GPR_E_INVALID, "gpr_agent_views: same-step autoreset needs final_achieved_goal / final_desired_goal bound in `out` "
+                                        "(the per-agent reward of an env that ended is computed from its terminal state)");
+    KParams P = make_params(env, out, true);
     const int obs_dim = env->cfg.num_movers * 2 * (env->cfg.learn_jerk ? 2 : 1);
     hipError_t he = env->cfg.precision == GPR_PRECISION_F64
-                        ? launch_agent_views<double>(P, env->lpe, obs_dim, observation_dev, achieved_goal_dev, desired_goal_dev, reward_dev, agent_obs_dev, agent_reward_dev, as_stream(hip_stream))
-                        : launch_agent_views<float>(P, env->lpe, obs_dim, observation_dev, achieved_goal_dev, desired_goal_dev, reward_dev, agent_obs_dev, agent_reward_dev, as_stream(hip_stream));
+                        ? launch_agent_views<double>(P, env->lpe, obs_dim, agent_obs_dev, agent_reward_dev, as_stream(hip_stream))
+                        : launch_agent_views<float>(P, env->lpe, obs_dim, agent_obs_dev, agent_reward_dev, as_stream(hip_stream));
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "agent views kernel launch");
 }
 

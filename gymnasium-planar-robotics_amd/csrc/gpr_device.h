@@ -53,6 +53,7 @@ struct KParams {
     void *obs, *ag, *dg, *reward;
     uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
     void *final_obs, *final_ag, *final_dg;
+    uint32_t *counters;         // [wavefronts][6] episode counters (include/gpr.h: GPR_CNT_*), NULL = not counting
     unsigned int *wave_timing;  // debug builds (-DGPR_WAVE_TIMING): 8 words per wavefront of the step kernel, else NULL
 };
 // BenchmarkPushingEnv additions (include/gpr.h: gpr_push_params), in the compute type

@@ -265,7 +265,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 
 #ifdef GPR_WAVE_TIMING
     const long long wt0 = __builtin_amdgcn_s_memtime();
-    int wt_clamp = 0, wt_near = 0, wt_served = 0, wt_rows = 0, wt_direct = 0, wt_due = 0;
+    int wt_clamp = 0, wt_near = 0, wt_served = 0, wt_rows = 0, wt_direct = 0, wt_due = 0, wt_exact = 0;
+    long long wt_loop0 = 0, wt_loop1 = 0;
 #define GPR_WT(x) x
 #else
 #define GPR_WT(x)
@@ -295,6 +296,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     R2<RT> acc{(RT)0, (RT)0};
     if constexpr (JERK) acc = load2<ST, RT>(P.acc, idx);
     int el = P.elapsed[envc];
+    // episode counters (include/gpr.h: GPR_CNT_*): lanes 0..5 of a wavefront own the six words of the wavefront's row
+    uint32_t cnt_old = 0u;
+    const int64_t cnt_row = t >> 6;
+    if ((P.counters != nullptr) & (__lane_id() < 6u)) cnt_old = P.counters[cnt_row * 6 + __lane_id()];
     if (mv >= M) { p.x = p.y = far_away<RT>(); v.x = v.y = (RT)0; a.x = a.y = (RT)0; acc.x = acc.y = (RT)0; }  // group padding
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
     const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
@@ -368,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // does (the thresholds are then set so that every shortcut test fails) and the tests compare. Lanes that must not vote
     // (dead / padding lanes, frozen envs) are taken out through per-lane thresholds instead of scalar mask arithmetic.
     // ---------------------------------------------------------------------------------------------------------------
-    constexpr int KC1 = 3, KC2 = 10, KC3 = 40;
+    constexpr int KC1 = 3, KC2 = 11, KC3 = 39;  // rungs of the clamp ladder: 1, 3 and 10 blocks of KB = 4 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
     // Box shape on a grid without holes: noise-free the rectangle is axis-aligned (identity quaternion), so its wall test is the
@@ -416,13 +421,51 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     bool vn_on = !every;                  // false: every lane draws per cycle (eager mode, > VN_ROWS needy lanes, > 64 cycles)
     unsigned long long vn_uncovered = ~0ull;  // lanes that may NOT simply read their row: no row of their own yet (or !vn_on: all)
     const R2<RT> q0{p0.x - (RT)0.5 * (C.gx0 + C.gx1), p0.y - (RT)0.5 * (C.gy0 + C.gy1)};
-    for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
+    // Shared arithmetic of the state update, written once so that every path below rounds identically (explicit fma's: the
+    // results must not depend on which contraction the compiler picks in which context).
+    auto speed2 = [&](R2<RT> t) { return __builtin_fmaf(t.x, t.x, t.y * t.y); };
+    auto integrate = [&](R2<RT> dvn) {  // mj_step (BE:1882): semi-implicit Euler on the displacements
+        dv = dvn;
+        v.x = v0.x + dv.x; v.y = v0.y + dv.y;
+        dp.x = __builtin_fmaf(dt_l, v.x, dp.x); dp.y = __builtin_fmaf(dt_l, v.y, dp.y);  // the position moves with the NEW velocity
+    };
+    // PL:634-643 on t = v_read + dt a (v_read = v + nv): clamped lanes get dv' = (v_max t/|t| - nv) - v0
+    auto clamp_dv = [&](R2<RT> t, R2<RT> nv, RT n2, R2<RT> dvn) {
+        const bool cl = n2 >= vmax2_l;  // PL:634, inclusive
+        const RT sc = C.v_max * Math<RT>::rsqrt_(n2);
+        dvn.x = cl ? __builtin_fmaf(t.x, sc, -nv.x) - v0.x : dvn.x;
+        dvn.y = cl ? __builtin_fmaf(t.y, sc, -nv.y) - v0.y : dvn.y;
+        return dvn;
+    };
+    // Velocity readings (PL:430) matter only to the lanes inside the clamp band -- one or two lanes of the wavefront, the same
+    // ones for the rest of the env-step -- and a reading is a pure function of (lane key, cycle). So when a lane first needs
+    // one, the 64 lanes draw, once, THAT lane's readings for cycles 0..63 (lane c draws cycle c) into a row of LDS; from then
+    // on a cycle costs every lane one ds_read (its own row, or the all-zero row) instead of a Box-Muller draw of which 63
+    // results are not looked at. Returns false when the rows are (or have to be) given up: then every lane draws per cycle.
+    auto build_rows = [&](unsigned long long fresh) {
+        if (!vn_on) return false;
+        for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
+            if ((vn_rows == VN_ROWS) | (P.num_cycles > 64)) { vn_on = false; vn_uncovered = ~0ull; return false; }
+            const int L = __builtin_ctzll(f);
+            const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+            const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
+            ++vn_rows;
+            GPR_WT(++wt_rows;)
+            vn_tab[vn_wave][vn_rows][__lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
+            if ((int)__lane_id() == L) vn_ptr = &vn_tab[vn_wave][vn_rows][0];
+            vn_uncovered &= ~(1ull << L);
+        }
+        return true;
+    };
+
+    // ---- one control cycle, everything evaluated in its place: the path of the cycles in which something may happen ----
+    auto exact_cycle = [&](int cyc) __attribute__((always_inline)) {
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
         R2<RT> dvn{dv.x + dtl.x, dv.y + dtl.y};
         if (cyc >= next_c) {
             GPR_WT(++wt_due;)
             R2<RT> t{v.x + dtl.x, v.y + dtl.y};
-            RT n2 = t.x * t.x + t.y * t.y;
+            RT n2 = speed2(t);
             float2 vn_r = make_float2(0.f, 0.f);
             if constexpr (NOISE) vn_r = vn_ptr[cyc & 63];  // issued here so that its LDS latency hides behind the tests below
             const unsigned long long needm = __ballot(!(n2 < vneed2_l));
@@ -433,50 +476,24 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 GPR_WT(++wt_clamp;)
                 R2<RT> nv{(RT)0, (RT)0};
                 if constexpr (NOISE) {
-                    // Velocity readings (PL:430) matter only to the lanes inside the clamp band -- one or two lanes of the
-                    // wavefront, the same ones for the rest of the env-step -- and a reading is a pure function of (lane key,
-                    // cycle). So when a lane first needs one, the 64 lanes draw, once, THAT lane's readings for cycles 0..63 (lane
-                    // c draws cycle c) into a row of LDS; from then on a cycle costs every lane one ds_read (its own row, or the
-                    // all-zero row) instead of a Box-Muller draw of which 63 results are not looked at. The kernel lasts as long
-                    // as its slowest wavefront, and that is one that clamps in all 40 cycles: this is where its time goes.
                     const unsigned long long fresh = needm & vn_uncovered;
                     if (fresh == 0ull) {  // the steady state: one scalar decision, the reading is already on its way
                         nv.x = vn_r.x; nv.y = vn_r.y;
+                    } else if (build_rows(fresh)) {
+                        const float2 r = vn_ptr[cyc];
+                        nv.x = r.x; nv.y = r.y;
                     } else {
-                        if (vn_on) {
-                            for (unsigned long long f = fresh; f != 0ull; f &= f - 1ull) {
-                                if ((vn_rows == VN_ROWS) | (P.num_cycles > 64)) { vn_on = false; vn_uncovered = ~0ull; break; }
-                                const int L = __builtin_ctzll(f);
-                                const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
-                                const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
-                                ++vn_rows;
-                                GPR_WT(++wt_rows;)
-                                vn_tab[vn_wave][vn_rows][__lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
-                                if ((int)__lane_id() == L) vn_ptr = &vn_tab[vn_wave][vn_rows][0];
-                                vn_uncovered &= ~(1ull << L);
-                            }
-                        }
-                        if (vn_on) {
-                            const float2 r = vn_ptr[cyc];
-                            nv.x = r.x; nv.y = r.y;
-                        } else {
-                            GPR_WT(++wt_direct;)
-                            const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
-                            nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
-                        }
+                        GPR_WT(++wt_direct;)
+                        const R2<RT> n = rng_normal_pair<RT>(key, draw_index(cyc, 0u));
+                        nv.x = C.sig_v * n.x; nv.y = C.sig_v * n.y;
                     }
                     t.x += nv.x; t.y += nv.y;
-                    n2 = t.x * t.x + t.y * t.y;
+                    n2 = speed2(t);
                 }
-                const bool cl = n2 >= vmax2_l;  // PL:634, inclusive
-                const RT sc = C.v_max * Math<RT>::rsqrt_(n2);
-                dvn.x = cl ? (t.x * sc - nv.x) - v0.x : dvn.x;
-                dvn.y = cl ? (t.y * sc - nv.y) - v0.y : dvn.y;
+                dvn = clamp_dv(t, nv, n2, dvn);
             }
         }
-        dv = dvn;
-        v.x = v0.x + dv.x; v.y = v0.y + dv.y;
-        dp.x += dt_l * v.x; dp.y += dt_l * v.y;  // semi-implicit Euler: the position moves with the NEW velocity
+        integrate(dvn);
         // the checks work on q = p - grid centre = q0 + dp (pair distances do not care, the wall reach wants it anyway);
         // p itself is only needed by the table-driven wall check of general layouts, by noisy reads, and after the loop
         const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
@@ -501,7 +518,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 sp_p = __ballot(near_b);
             }
         }
-        if ((sp_w | sp_p) == 0ull) continue;
+        if ((sp_w | sp_p) == 0ull) return;
         GPR_WT(++wt_near;)
         p.x = p0.x + dp.x; p.y = p0.y + dp.y;
         // ---- something is close: the exact checks, each on its own noisy position read ----
@@ -564,7 +581,121 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 if ((P.autoreset == 1) & live & (mv == 0) & !queued) enqueue(false);  // a collision ends the env (PL:478): reset it
             }
         }
+    };
+
+    // BLOCKS OF KB CYCLES, CHECKED AFTERWARDS (grids without holes, circles). A SIMD of this machine retires a plain vector
+    // instruction every ~2.5 clocks and a packed one every ~5 with the four wavefronts this workload gives it, and every
+    // wave-level decision (v_cmp -> SGPR -> s_cbranch) stalls its wavefront for 40-60 clocks (scratch/ubench/simd.hip,
+    // cycle.hip). So a block of KB cycles runs straight-line: integrate, wall reach and pair sweep of every cycle, each
+    // cycle's state and reaches kept in registers, the closest approach to a wall / to another mover as a running max / min --
+    // and ONE decision at the block's end: did anything come within the noise band of a threshold? If not (the common case) the
+    // block is done. If so, the flagged cycles are looked at in order, each with exact_cycle's noisy tests on the state saved
+    // for that cycle; an env that collides is rolled back to the state of its colliding cycle (BE:1904-1905) and taken out,
+    // which also takes it out of the tests of the block's later cycles. Same operations in the same order as the
+    // cycle-by-cycle path, so the results are bit-identical to it (GPR_EAGER_NOISE=1 runs only exact_cycle; tests compare).
+    // The speed clamp: lanes that may reach the limit inside the block (the rung test of the cycle-by-cycle ladder) make the
+    // wavefront run the block's clamp form, in which every lane evaluates PL:634-643 branch-free on its reading from LDS
+    // (lanes without a row read zeros and cannot clamp).
+    GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
+    constexpr int KB = 4;
+    static_assert(KC1 == KB - 1, "the first rung covers exactly one block");
+    const bool fast_ok = FULL && SHAPE == 0 && !every;
+    for (int cyc = 0; cyc < P.num_cycles;) {  // BE:1879
+        int n_exact = P.num_cycles - cyc;
+        if (fast_ok & (cyc + KB <= P.num_cycles)) {
+            unsigned long long needy = 0ull;
+            bool rows_ok = true;
+            if (cyc + KB - 1 >= next_c) {
+                const RT n2 = speed2(R2<RT>{v.x + dtl.x, v.y + dtl.y});
+                needy = __ballot(!(n2 < c1r));
+                if (needy == 0ull) {
+                    next_c = cyc + 1 + (__ballot(!(n2 < c2r)) != 0ull ? KC1 : __ballot(!(n2 < c3r)) != 0ull ? KC2 : KC3);
+                } else if constexpr (NOISE) {
+                    const unsigned long long fresh = needy & vn_uncovered;
+                    if (fresh != 0ull) rows_ok = build_rows(fresh);
+                }
+            }
+            if (rows_ok) {
+                R2<RT> dps[KB], dvs[KB];
+                RT es[KB], ms[KB];
+                RT eacc = -INF, macc = INF;
+                if (needy == 0ull) {
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        integrate(R2<RT>{dv.x + dtl.x, dv.y + dtl.y});
+                        const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
+                        dps[j] = dp; dvs[j] = dv;
+                        es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
+                        eacc = __builtin_fmaxf(eacc, es[j]);
+                        ms[j] = INF;
+                        if constexpr (LPE > 1) { ms[j] = pair_min_dist<RT, LPE>(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                    }
+                } else {
+                    GPR_WT(wt_clamp += KB;)
+                    float2 rd[KB];
+                    if constexpr (NOISE) {
+#pragma unroll
+                        for (int j = 0; j < KB; ++j) rd[j] = vn_ptr[(cyc + j) & 63];
+                    }
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        R2<RT> t{v.x + dtl.x, v.y + dtl.y}, nv{(RT)0, (RT)0};
+                        if constexpr (NOISE) { nv.x = rd[j].x; nv.y = rd[j].y; t.x += nv.x; t.y += nv.y; }
+                        integrate(clamp_dv(t, nv, speed2(t), R2<RT>{dv.x + dtl.x, dv.y + dtl.y}));
+                        const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
+                        dps[j] = dp; dvs[j] = dv;
+                        es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
+                        eacc = __builtin_fmaxf(eacc, es[j]);
+                        ms[j] = INF;
+                        if constexpr (LPE > 1) { ms[j] = pair_min_dist<RT, LPE>(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                    }
+                }
+                if ((__ballot(!(eacc < w0)) | __ballot(macc <= p0r)) != 0ull) {
+                    GPR_WT(++wt_near;)
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        // (w0 / p0r / wx_l / pthr_l of an env that collided in an earlier cycle of this block are +inf / -1 by now)
+                        if ((__ballot(!(es[j] < w0)) | __ballot(ms[j] <= p0r)) == 0ull) continue;
+                        GPR_WT(++wt_exact;)
+                        const R2<RT> pj{p0.x + dps[j].x, p0.y + dps[j].y};
+                        unsigned long long wraw = __ballot(!(es[j] < wx_l)), hraw = 0ull;
+                        if constexpr (NOISE) {
+                            if (__ballot(!(__builtin_fabsf(wx_l - es[j]) > wband)) != 0ull) {
+                                const R2<RT> pw = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u));
+                                wraw = __ballot(!(wall_reach_full<RT>(C, pw.x, pw.y, cw_step) < wx_l));
+                            }
+                        }
+                        if constexpr (LPE > 1) {
+                            hraw = __ballot(ms[j] <= pthr_l);  // BE:409, inclusive
+                            if constexpr (NOISE) {
+                                if (__ballot(absr(ms[j] - pthr_l) <= pband) != 0ull) {
+                                    const R2<RT> pp = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u + R));
+                                    hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
+                                }
+                            }
+                        }
+                        if ((wraw | hraw) != 0ull) {  // BE:1904-1905: the env stops in this cycle
+                            wc_m |= wraw;
+                            mc_m |= hraw;
+                            const unsigned long long nf = group_or<LPE>(wraw | hraw);
+                            frozen_m |= nf;
+                            if (lane_of(nf)) {
+                                dp = dps[j]; dv = dvs[j];
+                                dtl.x = dtl.y = (RT)0; dt_l = (RT)0; vmax2_l = INF; GPR_LANE_OUT();
+                                if ((P.autoreset == 1) & live & (mv == 0) & !queued) enqueue(false);
+                            }
+                        }
+                    }
+                    v.x = v0.x + dv.x; v.y = v0.y + dv.y;
+                }
+                cyc += KB;
+                continue;
+            }
+            n_exact = KB;
+        }
+        for (int j = 0; j < n_exact; ++j, ++cyc) exact_cycle(cyc);
     }
+    GPR_WT(wt_loop1 = __builtin_amdgcn_s_memtime();)
     p.x = p0.x + dp.x; p.y = p0.y + dp.y;
 #undef GPR_LANE_OUT
     } else {
@@ -743,6 +874,15 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const bool need = live_env & (reset_first | ((P.autoreset == 1) & done));
     if ((P.autoreset == 2) & done) el_new = -1;
     if (need) el_new = 0;
+    if (P.counters != nullptr) {  // wave-uniform; popcounts of the per-env flags (one bit per env: its mover-0 lane)
+        const unsigned long long head = __ballot(live & (mv == 0) & !reset_first);
+        const uint32_t c0 = (uint32_t)__popcll(__ballot(done) & head), c1 = (uint32_t)__popcll(__ballot(o.terminated) & head);
+        const uint32_t c2 = (uint32_t)__popcll(__ballot(trunc) & head), c3 = (uint32_t)__popcll(__ballot(o.is_success) & head);
+        const uint32_t c4 = (uint32_t)__popcll(__ballot(wc) & head), c5 = (uint32_t)__popcll(__ballot(mc) & head);
+        const uint32_t L = __lane_id();
+        const uint32_t add = L == 0u ? c0 : L == 1u ? c1 : L == 2u ? c2 : L == 3u ? c3 : L == 4u ? c4 : c5;
+        if (L < 6u) P.counters[cnt_row * 6 + L] = cnt_old + add;
+    }
 
     // What the stepping wavefront stores: everything of the envs that go on, and of an env that ended in this call its
     // terminal observation (same-step mode: final_*) and the step's scalars. The reset itself -- new state, goal and
@@ -836,9 +976,12 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
 #ifdef GPR_WAVE_TIMING
     if (P.wave_timing && (threadIdx.x & 63) == 0) {  // clocks: cycles + own stores | queue service incl. waiting; counts
         const long long wt2 = __builtin_amdgcn_s_memtime();
-        unsigned int *d = P.wave_timing + 8 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+        unsigned int *d = P.wave_timing + 16 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
         d[0] = (unsigned)(wt1 - wt0); d[1] = (unsigned)(wt2 - wt1); d[2] = (unsigned)wt_clamp; d[3] = (unsigned)wt_near; d[4] = (unsigned)wt_served;
         d[5] = (unsigned)wt_rows; d[6] = (unsigned)wt_direct; d[7] = (unsigned)wt_due;
+        d[8] = (unsigned)(wt_loop0 - wt0); d[9] = (unsigned)(wt_loop1 - wt_loop0); d[10] = (unsigned)(wt1 - wt_loop1); d[11] = (unsigned)wt_exact;
+        d[12] = (unsigned)wt0; d[13] = (unsigned)wt2;  // low words of the absolute clock: start / end of the wavefront
+        d[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_ID, XCC_ID
     }
 #endif
 #undef GPR_WT

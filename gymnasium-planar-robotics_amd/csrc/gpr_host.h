@@ -7,8 +7,10 @@ namespace gpr {
 // fused env kernels, one instantiation per (storage, compute) precision, each in its own translation unit
 template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s);
 
-template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, const void *obs, const void *ag, const void *dg,
-                                                     const void *reward, void *agent_obs, void *agent_reward, hipStream_t s);
+// P carries the step outputs (obs / ag / dg / reward / terminated / truncated / final_*) the views are built from
+template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, void *agent_obs, void *agent_reward, hipStream_t s);
+// sums the per-wavefront episode counters [rows][6] into totals[6] (uint64, added) and clears the rows
+hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, hipStream_t s);
 
 // BenchmarkPushingEnv kernels (gpr_push_kernels.hip)
 template <typename ST, typename RT> hipError_t launch_push(bool is_reset, const KParams &P, const PushCst<RT> &Q, const PushPtrs &X, hipStream_t s);

@@ -139,9 +139,10 @@ template <typename ST, int LPE, int D> struct AgentGather {
     }
 };
 template <typename ST, int LPE>
-__global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_dim, const ST *obs, const ST *ag, const ST *dg, const ST *reward,
-                                                       ST *agent_obs, ST *agent_reward) {
+__global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_dim, ST *agent_obs, ST *agent_reward) {
     const int M = P.M;
+    const ST *obs = static_cast<const ST *>(P.obs), *ag = static_cast<const ST *>(P.ag), *dg = static_cast<const ST *>(P.dg);
+    const ST *reward = static_cast<const ST *>(P.reward);
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int mv = (int)(t & (LPE - 1));
     const int64_t env = t / LPE;
@@ -155,17 +156,24 @@ __global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_
     if (live) { row[0] = vx; row[1] = vy; row[2] = px; row[3] = py; row[4] = gx; row[5] = gy; }
     AgentGather<ST, LPE, 1>::run(px, py, vx, vy, live ? mv : LPE, M, row);  // dead lanes write nothing (mv = LPE fails mv < M)
     if (live) {
-        const double r = (double)reward[envc], rs = P.cd.reward_success, dx = (double)px - (double)gx, dy = (double)py - (double)gy;
+        // The env reward (PL:519-531) was computed from the state the step ended in. With same-step autoreset an env that ended
+        // in this call already shows the new episode in obs / ag / dg: its terminal achieved / desired goal are in final_*.
+        ST rpx = px, rpy = py, rgx = gx, rgy = gy;
+        const bool ended = (P.autoreset == 1) & ((P.terminated[envc] | P.truncated[envc]) != 0);
+        if (ended & (P.final_ag != nullptr)) {
+            const ST *fa = static_cast<const ST *>(P.final_ag), *fd = static_cast<const ST *>(P.final_dg);
+            rpx = fa[envc * 2 * M + 2 * mvc]; rpy = fa[envc * 2 * M + 2 * mvc + 1];
+            rgx = fd[envc * 2 * M + 2 * mvc]; rgy = fd[envc * 2 * M + 2 * mvc + 1];
+        }
+        const double r = (double)reward[envc], rs = P.cd.reward_success, dx = (double)rpx - (double)rgx, dy = (double)rpy - (double)rgy;
         const bool shared = (r == rs) | (r == -rs);  // PL:529-531
         agent_reward[envc * M + mvc] = shared ? (ST)r : (ST)(sqrt(dx * dx + dy * dy) <= P.cd.thr ? 0.0 : -1.0);
     }
 }
-template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, const void *obs, const void *ag, const void *dg,
-                                                     const void *reward, void *agent_obs, void *agent_reward, hipStream_t s) {
+template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, void *agent_obs, void *agent_reward, hipStream_t s) {
     const unsigned grid = grid_for(P.E * lpe);
     auto a = [&](auto K) {
-        hipLaunchKernelGGL(K, dim3(grid), dim3(BLOCK), 0, s, P, obs_dim, static_cast<const ST *>(obs), static_cast<const ST *>(ag),
-                           static_cast<const ST *>(dg), static_cast<const ST *>(reward), static_cast<ST *>(agent_obs), static_cast<ST *>(agent_reward));
+        hipLaunchKernelGGL(K, dim3(grid), dim3(BLOCK), 0, s, P, obs_dim, static_cast<ST *>(agent_obs), static_cast<ST *>(agent_reward));
     };
     switch (lpe) {
         case 1: a(k_agent_views<ST, 1>); break;
@@ -177,8 +185,35 @@ template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, 
     }
     return hipGetLastError();
 }
-template hipError_t launch_agent_views<float>(const KParams &, int, int, const void *, const void *, const void *, const void *, void *, void *, hipStream_t);
-template hipError_t launch_agent_views<double>(const KParams &, int, int, const void *, const void *, const void *, const void *, void *, void *, hipStream_t);
+template hipError_t launch_agent_views<float>(const KParams &, int, int, void *, void *, hipStream_t);
+template hipError_t launch_agent_views<double>(const KParams &, int, int, void *, void *, hipStream_t);
+
+// episode counters: one block sums the per-wavefront rows (a few thousand) column by column, adds to the caller's totals,
+// clears the rows. Runs on the stream of the step kernels, so it sees complete rows.
+__global__ void __launch_bounds__(BLOCK) k_counter_reduce(uint32_t *rows, int64_t n_rows, unsigned long long *totals) {
+    __shared__ unsigned long long part[BLOCK / 64][6];
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t r = threadIdx.x; r < n_rows; r += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { acc[k] += rows[r * 6 + k]; rows[r * 6 + k] = 0u; }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long v = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) v += part[w][threadIdx.x];
+        totals[threadIdx.x] += v;
+    }
+}
+hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, hipStream_t s) {
+    hipLaunchKernelGGL(k_counter_reduce, dim3(1), dim3(BLOCK), 0, s, rows, n_rows, reinterpret_cast<unsigned long long *>(totals));
+    return hipGetLastError();
+}
 
 hipError_t launch_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2, uint8_t *out, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_segments, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, p1, p2, q1, q2, out);

@@ -246,6 +246,65 @@ class VecBasicPlanarRoboticsEnv:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # ------------------------------------------------------------------------------------------------------------
+    # engine additions with no reference counterpart: resumable random streams, checkpoints, episode counters
+    # ------------------------------------------------------------------------------------------------------------
+    def get_rng_state(self) -> tuple[int, int]:
+        """(seed, tick) of the handle's counter-based random streams (RNG spec gpr-rng-v1, include/gpr.h)."""
+        seed, tick = C.c_uint64(), C.c_uint64()
+        _native.check(self._lib.gpr_get_rng_state(self._handle, C.byref(seed), C.byref(tick)), self._handle)
+        return int(seed.value), int(tick.value)
+
+    def set_rng_state(self, seed: int, tick: int) -> None:
+        _native.check(self._lib.gpr_set_rng_state(self._handle, int(seed), int(tick)), self._handle)
+        self._needs_seed = False
+
+    def _state_tensors(self) -> dict[str, torch.Tensor]:
+        raise NotImplementedError
+
+    def state_dict(self) -> dict[str, Any]:
+        """Everything a run consists of: the state tensors (cloned) and the position of the random streams. ``torch.save`` it;
+        ``load_state_dict`` on an env of the same configuration continues the run bit for bit."""
+        seed, tick = self.get_rng_state()
+        return {'rng_seed': seed, 'rng_tick': tick, **{k: v.detach().clone() for k, v in self._state_tensors().items()}}
+
+    def load_state_dict(self, sd: dict[str, Any]) -> None:
+        for k, v in self._state_tensors().items():
+            v.copy_(torch.as_tensor(sd[k]).to(device=v.device, dtype=v.dtype))
+        self.set_rng_state(sd['rng_seed'], sd['rng_tick'])
+
+    def enable_episode_counters(self, enable: bool = True) -> None:
+        """Let the step kernels count episode ends on the device (per-wavefront popcounts of the done masks; no host sync)."""
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.gpr_enable_counters(self._handle, int(enable)), self._handle)
+        if not hasattr(self, '_counter_totals'):
+            self._counter_totals = torch.zeros(len(_native.COUNTERS), dtype=torch.int64, device=self.device)
+        self._counters_on = bool(enable)
+
+    def read_episode_counters(self) -> torch.Tensor:
+        """int64 device tensor [6] = running totals in the order of ``_native.COUNTERS`` (episodes, terminated, truncated, success,
+        wall_collision, mover_collision) since ``enable_episode_counters``. One tiny reduce kernel, no host sync."""
+        assert getattr(self, '_counters_on', False), 'call enable_episode_counters() first'
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.gpr_read_counters(self._handle, self._counter_totals.data_ptr(), self._stream()), self._handle)
+        return self._counter_totals
+
+    def all_reduce_episode_counters(self) -> torch.Tensor:
+        """Job-wide totals: ONE all_reduce (SUM) of the six counters over the default process group -- the only collective a
+        rollout flush needs when every rank's learner consumes its own shard."""
+        import torch.distributed as dist
+        if not getattr(self, '_counters_on', False):
+            self.enable_episode_counters()
+        tot = self.read_episode_counters().clone()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == 'gloo':
+                host = tot.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                tot = host.to(self.device)
+            else:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        return tot
+
     def _dev_f64(self, a) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=torch.float64).contiguous()

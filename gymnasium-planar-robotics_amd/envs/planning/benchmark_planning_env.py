@@ -162,6 +162,9 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
             self._final['desired_goal'].data_ptr() if use_final else None)
         self._needs_seed = True
 
+    def _state_tensors(self) -> dict[str, torch.Tensor]:
+        return {'pos': self.pos, 'vel': self.vel, 'acc': self.acc, 'goals': self.goals, 'elapsed_steps': self.elapsed_steps}
+
     # ------------------------------------------------------------------------------------------------------------
     # Gymnasium-style API, batched
     # ------------------------------------------------------------------------------------------------------------

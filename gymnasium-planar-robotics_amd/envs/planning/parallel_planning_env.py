@@ -10,7 +10,9 @@ this engine's own definition (include/gpr.h, ``gpr_agent_views``):
 * ``observations[agent]`` ``[E, 4M+2]``: own velocity, own position, own goal, then for every other mover in ascending index its
   position and velocity relative to the agent (a lane-permute gather inside the env's wavefront group, no extra memory pass);
 * ``rewards[agent]`` ``[E]``: the env reward of PL:519-531 split per agent: -50 / +50 for every agent on collision / joint
-  success, otherwise -1 while the agent's own goal is not reached, 0 once it is (summing to the single-agent reward);
+  success, otherwise -1 while the agent's own goal is not reached, 0 once it is (summing to the single-agent reward). With
+  same-step autoreset the reward of an env that ended in this call (also by TimeLimit) is computed from its TERMINAL
+  achieved / desired goal (``info['final_obs']``), not from the first observation of the new episode;
 * ``terminations`` / ``truncations`` / ``infos``: the env's, shared by every agent.
 """
 from __future__ import annotations
@@ -55,9 +57,8 @@ class VecBenchmarkPlanningParallelEnv:
     def _views(self):
         e = self.env
         with torch.cuda.device(e.device):
-            _native.check(e._lib.gpr_agent_views(e._handle, e._obs['observation'].data_ptr(), e._obs['achieved_goal'].data_ptr(),
-                                                 e._obs['desired_goal'].data_ptr(), e._reward.data_ptr(), self._agent_obs.data_ptr(),
-                                                 self._agent_reward.data_ptr(), e._stream()), e._handle)
+            _native.check(e._lib.gpr_agent_views(e._handle, C.byref(e._out), self._agent_obs.data_ptr(), self._agent_reward.data_ptr(),
+                                                 e._stream()), e._handle)
         return dict(self._obs_views), dict(self._rew_views)
 
     def reset(self, seed: int | None = None, options: dict | None = None):

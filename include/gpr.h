@@ -106,11 +106,33 @@ const char *gpr_last_error(const gpr_env *env);
 int gpr_bind_state(gpr_env *env, const gpr_state *state);
 /* reset(seed=...) part of BE:1789-1791: re-keys every random stream and restarts the call counter */
 int gpr_seed(gpr_env *env, uint64_t seed);
+/* Position of the handle's random streams (RNG spec gpr-rng-v1: every draw is a pure function of seed, call counter `tick`, kind,
+ * global env id, mover, draw index). Together with the caller-owned gpr_state tensors this is ALL the state of a run: save the
+ * pair next to the tensors, restore both into a fresh handle, and the run continues bit for bit (the reference checkpoints
+ * nothing; its counterpart is pickling `np_random` / `rng_noise`, BE:182,1789-1791). */
+int gpr_get_rng_state(const gpr_env *env, uint64_t *seed_out, uint64_t *tick_out);
+int gpr_set_rng_state(gpr_env *env, uint64_t seed, uint64_t tick);
 /* reset() (BE:1770-1833 + PL:355-418). mask_dev: nullable [E] bytes, non-zero = reset this env. Fills `out`
  * (reward 0, terminated/truncated 0) for the envs it resets. */
 int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream);
 /* step(action) (BE:1835-1950 + PL:420-450 + TimeLimit). action_dev: [E][2M] real, clipped to the action space. */
 int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
+
+/* Episode counters (engine addition, SURVEY.md section 5: the reference logs nothing). Every step kernel adds, per wavefront,
+ * the popcounts of its done masks to a small device table owned by the handle; gpr_read_counters sums that table into the
+ * caller's six uint64 totals (added to what is there), and clears the table. Counting starts with the first
+ * gpr_enable_counters(env, 1); while disabled the step kernels do not touch the table. */
+enum {
+    GPR_CNT_EPISODES = 0,     /* env-steps with terminated | truncated */
+    GPR_CNT_TERMINATED = 1,   /* PL:459-479 */
+    GPR_CNT_TRUNCATED = 2,    /* TimeLimit */
+    GPR_CNT_SUCCESS = 3,      /* info['is_success'] */
+    GPR_CNT_WALL = 4,         /* info['wall_collision'] */
+    GPR_CNT_PAIR = 5,         /* info['mover_collision'] */
+    GPR_NUM_COUNTERS = 6
+};
+int gpr_enable_counters(gpr_env *env, int32_t enable);
+int gpr_read_counters(gpr_env *env, uint64_t *totals_dev /* [GPR_NUM_COUNTERS], device, caller-owned */, void *hip_stream);
 /* compute_reward / compute_terminated on HER batches (PL:459-534): achieved/desired [batch][2M] real. */
 int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, const void *desired_dev,
                        const uint8_t *mover_collision_dev, const uint8_t *wall_collision_dev, void *reward_dev,
@@ -130,9 +152,11 @@ int gpr_check_mover_collision(gpr_env *env, int64_t batch, const double *qpos_de
  *                    ascending j: position of j relative to the agent (2), velocity of j relative to the agent (2)
  *   agent_reward_dev [E][M] real: the env reward of PL:519-531 split per agent -- -50 / +50 for every agent on collision /
  *                    success, otherwise -1 for an agent whose own goal is not reached (PL:524) and 0 for one that is
- * Inputs are the outputs of gpr_step / gpr_reset (observation [E][obs_dim], achieved_goal, desired_goal [E][2M], reward [E]). */
-int gpr_agent_views(gpr_env *env, const void *observation_dev, const void *achieved_goal_dev, const void *desired_goal_dev,
-                    const void *reward_dev, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream);
+ * Inputs are the outputs of gpr_step / gpr_reset as bound in `out` (observation [E][obs_dim], achieved_goal, desired_goal [E][2M],
+ * reward, terminated, truncated [E]). With same-step autoreset the observation of an env that ended in this call is already the
+ * new episode's; its per-agent REWARD is then computed from final_achieved_goal / final_desired_goal (the terminal state the env
+ * reward was computed from), which must be bound in `out` in that mode. */
+int gpr_agent_views(gpr_env *env, const gpr_step_out *out, void *agent_obs_dev, void *agent_reward_dev, void *hip_stream);
 
 /* ---- BenchmarkPushingEnv (gymnasium_planar_robotics/envs/manipulation/benchmark_pushing_env.py, "PU") -----------------
  * One mover pushes one box over 3x3 tiles. The handle is created by gpr_create with num_movers = 1, a 3x3 layout and the
