@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libgpr_hip.so')
+LIB_PATH = os.environ.get('GPR_LIB_PATH') or os.path.join(HERE, 'libgpr_hip.so')  # (override: A/B timing of two builds)
 MAX_MOVERS = 16
 
 OK, E_INVALID, E_HIP, E_UNBOUND, E_UNSUPPORTED = 0, -1, -2, -3, -4

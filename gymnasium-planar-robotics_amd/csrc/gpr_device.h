@@ -86,11 +86,29 @@ template <typename ST, typename RT> __device__ __forceinline__ R2<RT> load2(cons
     typename V2<ST>::type v = *reinterpret_cast<const typename V2<ST>::type *>(static_cast<const ST *>(base) + idx);
     return R2<RT>{(RT)v.x, (RT)v.y};
 }
+// State and observation stores are WRITE-THROUGH (sc1): they leave the CU while the other wavefronts still compute, and the
+// kernel ends without megabytes of dirty L2 lines to write back (a dependent kernel boundary costs its predecessor's dirty
+// bytes / 6 TB/s on this machine: MI355X_MICROARCH.md, row "boundary" -- ~1.9 us for the 11 MB one step writes).
 template <typename ST, typename RT> __device__ __forceinline__ void store2(void *base, int64_t idx, R2<RT> v) {
     typename V2<ST>::type o;
     o.x = (ST)v.x;
     o.y = (ST)v.y;
+#ifdef GPR_PLAIN_STORES
     *reinterpret_cast<typename V2<ST>::type *>(static_cast<ST *>(base) + idx) = o;
+#else
+    if constexpr (sizeof(ST) == 4) {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &o, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(static_cast<ST *>(base) + idx), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        unsigned long long b0, b1;
+        __builtin_memcpy(&b0, &o.x, 8);
+        __builtin_memcpy(&b1, &o.y, 8);
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(static_cast<ST *>(base) + idx);
+        __hip_atomic_store(d, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 }
 // value as it will read back from storage (float storage under double arithmetic rounds here)
 template <typename ST, typename RT> __device__ __forceinline__ RT stored(RT v) { return (RT)(ST)v; }

@@ -56,9 +56,17 @@ __device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint3
 
 // _reset_callback (PL:355-418) + the collision flags / observation of reset() (BE:1797-1831) for the env groups whose
 // `need` is set. Wave-cooperative: every lane of the wavefront must call it (it votes).
+//
+// PARALLEL TRIALS. The reference samples all movers of an env at once and rejects the whole set on any conflict
+// (PL:369-385: ~1.7 trials per reset with 4 movers, ~45 with 16). The draws are indexed by trial, so the candidate the
+// sequential loop accepts is simply the first valid one in trial order -- and S lane groups that all work on the SAME env
+// (S a power of two, wave-uniform; the S groups are adjacent and start at a multiple of S) find it S trials at a time:
+// group k of the set evaluates trial base + k, a ballot shows which are valid, the first one wins and its candidate is
+// fetched by ds_bpermute. S = 1 is the plain sequential loop (k_reset: one env per lane group). All S groups of a set
+// return the same p, g, flags and observation; the caller lets one of them store.
 template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE>
 __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, bool live,
-                                               bool need, RT c, RT c1, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
+                                               bool need, RT c, RT c1, int S, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
     const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);  // BE:487 with add_safety_offset=True
@@ -72,58 +80,87 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
     const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, (uint32_t)mvc);
     const RT sx = C.max_x - C.min_x, sy = C.max_y - C.min_y;
+    const int gi = (int)(__lane_id() / LPE);
+    const int slot = gi & (S - 1), lead_lane = (gi & ~(S - 1)) * LPE;  // my trial offset in a round; first lane of my env's set
+    const unsigned long long set_mask = S * LPE >= 64 ? ~0ull : ((1ull << (S * LPE)) - 1ull);
 
-    bool pending = need;
-    R2<RT> cand = p;
-    for (int trial = 0; trial < P.max_reset_trials; ++trial) {  // PL:369-385
-        if (__ballot(pending) == 0ull) break;
+    auto candidate = [&](uint32_t key, int trial) {
         R2<RT> cn;
-        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(ks, 2u * (uint32_t)trial));  // PL:377
-        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(ks, 2u * (uint32_t)trial + 1u));
+        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(key, 2u * (uint32_t)trial));  // PL:377 / PL:402
+        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(key, 2u * (uint32_t)trial + 1u));
         if (mv >= M) cn.x = cn.y = far_away<RT>();
-        bool w, hit;
-        if constexpr (SHAPE == 0) {
-            w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                   // PL:379
-            hit = live & dist_le<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.max_csum_safe);       // PL:381-383
+        return cn;
+    };
+    auto from_lane = [&](RT v, int lane) {  // the value `lane` holds (per-lane source)
+        if constexpr (sizeof(RT) == 4) {
+            return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)__float_as_uint(v)));
         } else {
-            const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
-            if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
-            else w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
-            hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
+            const uint64_t b = (uint64_t)__double_as_longlong(v);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)b);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)(b >> 32));
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         }
-        bool bad = group_any<LPE>(w | hit);
-        if (pending) { cand = cn; pending = bad; }
-    }
-    if (need) p = cand;
-
-    pending = need;
-    cand = g;
-    for (int trial = 0; trial < P.max_reset_trials; ++trial) {  // PL:395-413
-        if (__ballot(pending) == 0ull) break;
-        R2<RT> cn;
-        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(kg, 2u * (uint32_t)trial));  // PL:402
-        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(kg, 2u * (uint32_t)trial + 1u));
-        if (mv >= M) cn.x = cn.y = far_away<RT>();
-        bool w;  // PL:403-404
-        if constexpr (SHAPE == 0) {
-            w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);
-        } else if constexpr (FULL) {
-            w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);
-        } else {
-            w = live & !pos_valid_box<RT, false>(T, P, Pose<RT>{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0}, ws0, ws1, (RT)0, nullptr);
+    };
+    for (int pass = 0; pass < 2; ++pass) {  // 0: start positions (PL:369-385), 1: goals (PL:395-413)
+        const uint32_t key = pass == 0 ? ks : kg;
+        bool pending = need;
+        R2<RT> cand = pass == 0 ? p : g;
+        for (int base = 0; base < P.max_reset_trials; base += S) {
+            if (__ballot(pending) == 0ull) break;
+            const int trial = base + slot;
+            const R2<RT> cn = candidate(key, trial);
+            bool w, hit;
+            if constexpr (SHAPE == 0) {
+                w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                    // PL:379 / PL:403-404
+                const RT md = pair_min_dist<RT, LPE>(cn.x, cn.y);
+                hit = live & (pass == 0 ? dist_le<RT>(md, C.max_csum_safe) : dist_lt<RT>(md, C.min_goal_dist));  // PL:381-383 / PL:407-413
+            } else {
+                const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
+                if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
+                else w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
+                if (pass == 0) hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
+                else hit = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);
+            }
+            const bool bad = group_any<LPE>(w | hit);
+            if (S == 1) {  // (wave-uniform) the sequential form: the candidate stands as soon as it is valid, or as the last one
+                if (pending) { cand = cn; pending = bad; }
+            } else {
+                const unsigned long long okm = __ballot(pending & !bad & (trial < P.max_reset_trials));
+                const unsigned long long seg = (okm >> lead_lane) & set_mask;   // the valid trials of my env's set, in trial order
+                const int wlane = lead_lane + (__builtin_ctzll(seg | (1ull << 63)) & ~(LPE - 1)) + mv;  // (my mover in) the first valid group
+                const RT wx = from_lane(cn.x, wlane & 63), wy = from_lane(cn.y, wlane & 63);
+                if (pending & (seg != 0ull)) { cand.x = wx; cand.y = wy; pending = false; }
+            }
         }
-        bool close = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);  // PL:407-413, strict
-        bool bad = group_any<LPE>(w | close);
-        if (pending) { cand = cn; pending = bad; }
+        if ((S != 1) & pending) cand = candidate(key, P.max_reset_trials - 1);  // trials exhausted: the last candidate stands
+        if (need) { if (pass == 0) p = cand; else g = cand; }
     }
-    if (need) g = cand;
 
     // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
     if constexpr (SHAPE == 0) {
-        R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
-        wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
-        R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, R);
-        mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+        bool lazy_done = false;
+        if constexpr (!Math<RT>::literal) {
+            // throughput mode, as in the step loop: a noisy read is within band_p of the truth, so wherever the noise-free
+            // verdicts have more room than that they stand and the two draws are skipped (exact)
+            if (P.eager_noise == 0) {
+                bool w_unc;
+                const bool w_ok = pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_safe, C.band_p, &w_unc);
+                const RT band_pair = (RT)2 * C.band_p, thr2 = C.max_csum_step * C.max_csum_step;
+                const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
+                const bool p_unc = absr(md - thr2) <= (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
+                if (__ballot(live & need & (w_unc | p_unc)) == 0ull) {
+                    wc = group_any<LPE>(live & !w_ok);
+                    mc = group_any<LPE>(live & (md <= thr2));
+                    lazy_done = true;
+                }
+            }
+        }
+        if (!lazy_done) {
+            R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
+            wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
+            R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, R);
+            mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+        }
     } else {
         bool lazy_done = false;
         if constexpr (FULL) {
@@ -151,72 +188,6 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         }
     }
     return observe<ST, RT, LPE, NOISE>(P, kn, 2u * R, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
-}
-
-// The same reset for ONE env per wavefront, for wide env groups (LPE >= 8): the 64 / LPE lane groups evaluate 64 / LPE
-// consecutive rejection trials at once and the first valid one in trial order wins -- exactly the candidate the sequential
-// loop of group_reset accepts (the draws are indexed by trial), in 64 / LPE times fewer rounds. The reference samples all movers
-// at once and rejects the whole set on any conflict (PL:369-385): with 16 movers that is ~45 trials per reset.
-// Wave-cooperative and wave-uniform: every lane works on env `env_global`; all lane groups return the same p, g, flags.
-template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE>
-__device__ __forceinline__ Obs<RT> group_reset_wide(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, RT c, RT c1,
-                                                    R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
-    static_assert(LPE >= 8 && SHAPE == 0, "wide reset: circle shape, 8 or 16 lanes per env");
-    const Cst<RT> &C = cst<RT>(P);
-    const int M = P.M;
-    constexpr int G = 64 / LPE;
-    const int gi = (int)(__lane_id() / LPE);
-    const bool live = mv < M;
-    const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);
-    const uint32_t ks = rng_key(P, KIND_RESET_START, env_global, (uint32_t)mvc);
-    const uint32_t kg = rng_key(P, KIND_RESET_GOAL, env_global, (uint32_t)mvc);
-    const uint32_t kn = rng_key(P, KIND_RESET_NOISE, env_global, (uint32_t)mvc);
-    const RT sx = C.max_x - C.min_x, sy = C.max_y - C.min_y;
-    auto candidate = [&](uint32_t key, int trial) {
-        R2<RT> cn;
-        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(key, 2u * (uint32_t)trial));
-        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(key, 2u * (uint32_t)trial + 1u));
-        if (mv >= M) cn.x = cn.y = far_away<RT>();
-        return cn;
-    };
-    auto from_group = [&](RT v, int grp) {  // the value lane (grp, mv) holds
-        if constexpr (sizeof(RT) == 4) {
-            return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((grp * LPE + mv) << 2, (int)__float_as_uint(v)));
-        } else {
-            const uint64_t b = (uint64_t)__double_as_longlong(v);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((grp * LPE + mv) << 2, (int)(uint32_t)b);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((grp * LPE + mv) << 2, (int)(uint32_t)(b >> 32));
-            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-        }
-    };
-    for (int pass = 0; pass < 2; ++pass) {  // 0: start positions (PL:369-385), 1: goals (PL:395-413)
-        const uint32_t key = pass == 0 ? ks : kg;
-        bool found = false;
-        R2<RT> win{(RT)0, (RT)0};
-        for (int base = 0; base < P.max_reset_trials; base += G) {
-            const int trial = base + gi;
-            const R2<RT> cn = candidate(key, trial);
-            const bool w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);  // PL:379 / PL:403-404
-            const RT md = pair_min_dist<RT, LPE>(cn.x, cn.y);
-            const bool hit = live & (pass == 0 ? dist_le<RT>(md, C.max_csum_safe) : dist_lt<RT>(md, C.min_goal_dist));  // PL:381-383 / PL:407-413
-            const bool ok = !group_any<LPE>(w | hit) & (trial < P.max_reset_trials);
-            const unsigned long long okm = __ballot(ok);
-            if (okm != 0ull) {
-                const int grp = __builtin_ctzll(okm) / LPE;  // the first valid trial in trial order
-                win.x = from_group(cn.x, grp); win.y = from_group(cn.y, grp);
-                found = true;
-                break;
-            }
-        }
-        if (!found) win = candidate(key, P.max_reset_trials - 1);  // trials exhausted: the last candidate stands (as in group_reset)
-        if (pass == 0) p = win; else g = win;
-    }
-    // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
-    const R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
-    wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
-    const R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, 1u);
-    mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
-    return observe<ST, RT, LPE, NOISE>(P, kn, 2u, p, R2<RT>{(RT)0, (RT)0}, g, mc, wc, live);
 }
 
 template <typename ST, typename RT>
@@ -464,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         R2<RT> dvn{dv.x + dtl.x, dv.y + dtl.y};
         if (cyc >= next_c) {
             GPR_WT(++wt_due;)
-            R2<RT> t{v.x + dtl.x, v.y + dtl.y};
+            R2<RT> t{v0.x + dvn.x, v0.y + dvn.y};  // the velocity this cycle ends with unless the clamp fires
             RT n2 = speed2(t);
             float2 vn_r = make_float2(0.f, 0.f);
             if constexpr (NOISE) vn_r = vn_ptr[cyc & 63];  // issued here so that its LDS latency hides behind the tests below
@@ -597,6 +568,20 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // wavefront run the block's clamp form, in which every lane evaluates PL:634-643 branch-free on its reading from LDS
     // (lanes without a row read zeros and cannot clamp).
     GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
+    // BLOCKS OF KB CYCLES, CHECKED AFTERWARDS (grids without holes, circles). A SIMD of this machine retires a plain vector
+    // instruction every ~2.5 clocks and a packed one every ~5 with the four wavefronts this workload gives it, and every
+    // wave-level decision (v_cmp -> SGPR -> s_cbranch) stalls its wavefront for 40-60 clocks (scratch/ubench/simd.hip,
+    // cycle.hip). So a block of KB cycles runs straight-line: integrate, wall reach and pair sweep of every cycle, each
+    // cycle's state and reaches kept in registers, the closest approach to a wall / to another mover as a running max / min --
+    // and ONE decision at the block's end: did anything come within the noise band of a threshold? If not (the common case) the
+    // block is done. If so, the flagged cycles are looked at in order, each with exact_cycle's noisy tests on the state saved
+    // for that cycle; an env that collides is rolled back to the state of its colliding cycle (BE:1904-1905) and taken out,
+    // which also takes it out of the tests of the block's later cycles. Same operations in the same order as the
+    // cycle-by-cycle path, so the results are bit-identical to it (GPR_EAGER_NOISE=1 runs only exact_cycle; tests compare).
+    // The speed clamp: lanes that may reach the limit inside the block (the rung test of the cycle-by-cycle ladder) make the
+    // wavefront run the block's clamp form, in which every lane evaluates PL:634-643 branch-free on its reading from LDS
+    // (lanes without a row read zeros and cannot clamp).
+    GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
     constexpr int KB = 4;
     static_assert(KC1 == KB - 1, "the first rung covers exactly one block");
     const bool fast_ok = FULL && SHAPE == 0 && !every;
@@ -606,7 +591,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             unsigned long long needy = 0ull;
             bool rows_ok = true;
             if (cyc + KB - 1 >= next_c) {
-                const RT n2 = speed2(R2<RT>{v.x + dtl.x, v.y + dtl.y});
+                const RT n2 = speed2(R2<RT>{v0.x + (dv.x + dtl.x), v0.y + (dv.y + dtl.y)});
                 needy = __ballot(!(n2 < c1r));
                 if (needy == 0ull) {
                     next_c = cyc + 1 + (__ballot(!(n2 < c2r)) != 0ull ? KC1 : __ballot(!(n2 < c3r)) != 0ull ? KC2 : KC3);
@@ -639,9 +624,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                     }
 #pragma unroll
                     for (int j = 0; j < KB; ++j) {
-                        R2<RT> t{v.x + dtl.x, v.y + dtl.y}, nv{(RT)0, (RT)0};
+                        const R2<RT> dvn{dv.x + dtl.x, dv.y + dtl.y};
+                        R2<RT> t{v0.x + dvn.x, v0.y + dvn.y}, nv{(RT)0, (RT)0};
                         if constexpr (NOISE) { nv.x = rd[j].x; nv.y = rd[j].y; t.x += nv.x; t.y += nv.y; }
-                        integrate(clamp_dv(t, nv, speed2(t), R2<RT>{dv.x + dtl.x, dv.y + dtl.y}));
+                        integrate(clamp_dv(t, nv, speed2(t), dvn));
                         const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
                         dps[j] = dp; dvs[j] = dv;
                         es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
@@ -900,14 +886,14 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         if (need & (mv == 0) & !queued) enqueue(reset_first);  // (a success, or a collision found by the generic loop)
     }
 
-    // SERVING THE QUEUE: claim up to 64 / LPE queued envs at a time (one for wide env groups, whose lane groups try rejection
-    // trials in parallel) until nothing unclaimed is left. Whatever is queued later is served by a wavefront that finishes
-    // later -- at the latest by the one that queued it.
+    // SERVING THE QUEUE: claim up to 64 / LPE queued envs at a time until nothing unclaimed is left; the lane groups a claim
+    // leaves idle join the others as parallel trial slots (group_reset: S groups per env). Whatever is queued later is served
+    // by a wavefront that finishes later -- at the latest by the one that queued it.
     // A wavefront that finds the queue empty stays (sleeping between looks) until every wavefront of the block is through with
     // its cycles: the envs the slowest wavefront queues while it is still cycling are then reset before it is done, and
     // nothing but its own last-minute entries is left for the end. Every wavefront gets here without waiting for anything, so
     // the wait ends.
-    constexpr int EPW = (LPE >= 8 && SHAPE == 0) ? 1 : 64 / LPE;  // envs per claim
+    constexpr int EPW = 64 / LPE;  // envs per claim
     GPR_WT(const long long wt1 = __builtin_amdgcn_s_memtime();)
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
@@ -931,46 +917,30 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         n = __builtin_amdgcn_readfirstlane(n);
         if (n == 0) break;
         GPR_WT(wt_served += n;)
-        if constexpr (LPE >= 8 && SHAPE == 0) {
-            int entry;
-            do { entry = __hip_atomic_load(&reset_list[base], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
-            const int64_t renv = env_block_base + (entry >> 1);
-            const bool rfirst = (entry & 1) != 0;
-            R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
-            bool rwc, rmc;
-            const Obs<RT> ro = group_reset_wide<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, c, c1, rp, rg, rwc, rmc);
-            if (((threadIdx.x & 63) < LPE) & (mv < M)) {
-                const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
-                const R2<RT> zero{(RT)0, (RT)0};
-                store2<ST, RT>(P.pos, ridx, rp);
-                store2<ST, RT>(P.vel, ridx, zero);
-                if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
-                store2<ST, RT>(P.goal, ridx, rg);
-                store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
-                if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
-            }
-        } else {
-            const int slot = (int)(threadIdx.x & 63) / LPE;
-            const bool have = slot < n;
-            int entry;
-            do { entry = __hip_atomic_load(&reset_list[base + (have ? slot : 0)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
-            const int64_t renv = env_block_base + (entry >> 1);
-            const bool rfirst = (entry & 1) != 0;
-            const bool rlive = have & (mv < M);
-            R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
-            bool rwc, rmc;
-            const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, rp, rg, rwc, rmc);
-            if (rlive) {
-                const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
-                const R2<RT> zero{(RT)0, (RT)0};
-                store2<ST, RT>(P.pos, ridx, rp);
-                store2<ST, RT>(P.vel, ridx, zero);
-                if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
-                store2<ST, RT>(P.goal, ridx, rg);
-                store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
-                // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
-                if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
-            }
+        // S lane groups per claimed env: the largest power of two with n * S <= 64 / LPE
+        int S = 1;
+        while (2 * S * n <= EPW) S *= 2;
+        const int gi = (int)(threadIdx.x & 63) / LPE;
+        const int eslot = gi / S;
+        const bool have = eslot < n;
+        int entry;
+        do { entry = __hip_atomic_load(&reset_list[base + (have ? eslot : 0)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
+        const int64_t renv = env_block_base + (entry >> 1);
+        const bool rfirst = (entry & 1) != 0;
+        const bool rlive = have & (mv < M);
+        R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+        bool rwc, rmc;
+        const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc);
+        if (rlive & ((gi & (S - 1)) == 0)) {  // one group of the env's set stores
+            const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
+            const R2<RT> zero{(RT)0, (RT)0};
+            store2<ST, RT>(P.pos, ridx, rp);
+            store2<ST, RT>(P.vel, ridx, zero);
+            if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
+            store2<ST, RT>(P.goal, ridx, rg);
+            store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
+            // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
+            if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
         }
     }
 #ifdef GPR_WAVE_TIMING
@@ -1010,7 +980,7 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     if constexpr (!FULL || SHAPE == 1) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
-    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, p, g, wc, mc);
+    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, 1, p, g, wc, mc);
     if (live & need) {
         const R2<RT> zero{(RT)0, (RT)0};
         store2<ST, RT>(P.pos, idx, p);
