@@ -144,36 +144,31 @@ class Pass:
             torch.cuda.synchronize(self.device)
 
     def run(self, steps, warmup, min_seconds):
-        """-> (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region, R)"""
+        """-> (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region, R). R starts at 1 and
+        grows (identically on every rank: it follows the all-reduced wall time) until the region lasts min_seconds."""
         import torch
+        reps = 1
         with torch.cuda.device(self.device):
-            # pilot: the warm-up steps are timed (host clock) to size R
-            self.sync()
-            t0 = time.perf_counter()
-            self.do_steps(max(1, warmup))
-            self.sync()
-            est = (time.perf_counter() - t0) / max(1, warmup)
-            reps = max(1, int(math.ceil(min_seconds / max(1e-9, est * steps))))
-            if self.world > 1:
-                import torch.distributed as dist
-                r = torch.tensor([reps], device=self.device, dtype=torch.int64)
-                dist.all_reduce(r, op=dist.ReduceOp.MAX)
-                reps = int(r.item())
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.sync()
-            ev0.record()  # on the stream the kernels are launched on (torch's current stream is what step_into passes down)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                self.do_steps(steps)
-            ev1.record()
-            self.sync()
-            wall = time.perf_counter() - t0
-        gpu_ms = ev0.elapsed_time(ev1)
-        if self.world > 1:
-            import torch.distributed as dist
-            w = torch.tensor([wall], device=self.device, dtype=torch.float64)
-            dist.all_reduce(w, op=dist.ReduceOp.MAX)
-            wall = float(w.item())
+            self.do_steps(warmup)
+            for _ in range(6):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.sync()
+                ev0.record()  # on the stream the kernels are launched on (torch's current stream is what step_into passes down)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    self.do_steps(steps)
+                ev1.record()
+                self.sync()
+                wall = time.perf_counter() - t0
+                gpu_ms = ev0.elapsed_time(ev1)
+                if self.world > 1:
+                    import torch.distributed as dist
+                    w = torch.tensor([wall], device=self.device, dtype=torch.float64)
+                    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                    wall = float(w.item())
+                if wall >= min_seconds:
+                    break
+                reps = int(math.ceil(reps * min_seconds / max(wall, 1e-6) * 1.25))
         return wall, gpu_ms, reps
 
     def done_fraction(self):

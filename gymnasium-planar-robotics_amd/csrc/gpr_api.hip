@@ -319,6 +319,11 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
         gpr_destroy(e);
         return rc;
     }
+    if (e->tab_f64.bytes > 100u * 1024u) {  // (cannot happen with GPR_MAX_TILES = 4096: ~47 KB; the kernels stage the tables in LDS)
+        g_create_error = "tile tables exceed the LDS budget of the step kernels";
+        gpr_destroy(e);
+        return GPR_E_UNSUPPORTED;
+    }
     KParams &P = e->base;
     P.E = c.num_envs; P.env_id_offset = c.env_id_offset;
     P.M = c.num_movers; P.Tx = c.num_tiles_x; P.Ty = c.num_tiles_y; P.c_shape = c.c_shape;

@@ -1000,6 +1000,19 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
     const unsigned lds = (FULL && SHAPE == 0) ? 0u : P.table_bytes;
+    // the tile tables of a large layout (64 x 64 cells in f64: 47 KB) plus the kernels' static LDS exceed the 64 KB a launch
+    // gets by default: raise the kernel's limit once (gfx950 has 160 KB per CU; gpr_create bounds the table size)
+    if (lds > 32u * 1024u) {
+        static bool raised_reset = false, raised_step = false;
+        bool &raised = is_reset ? raised_reset : raised_step;
+        if (!raised) {
+            const void *fn = is_reset ? reinterpret_cast<const void *>(&k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
+                                      : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>);
+            const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            if (he != hipSuccess) return he;
+            raised = true;
+        }
+    }
     if (is_reset) {
         hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     } else {

@@ -1,5 +1,11 @@
-"""Multi-GPU plumbing: env batches shard embarrassingly (the reference is literally one env per process), so the only
-cross-GPU traffic is ONE RCCL all-gather of the rollout tensors when a rollout buffer is flushed.
+"""Multi-GPU plumbing: env batches shard embarrassingly (the reference is literally one env per process): ``step()`` and
+``reset()`` exchange nothing. What a rollout flush moves is the caller's choice:
+
+* nothing but the six episode counters (``env.all_reduce_episode_counters()``: ONE 48-byte all_reduce) when every rank's learner
+  consumes its own ``RolloutBuffer`` shard -- the default of ``bench.py``; at this engine's step rate a rank produces
+  ~134 B x 3.7e9 env-steps/s = 500 GB/s of rollout data, more than the xGMI links of a GPU can take in from seven peers;
+* a learner-sized minibatch (``RolloutBuffer.gather_minibatch``): ONE all-gather of [T, n, .] slices of the fields a learner reads;
+* the whole buffer (``RolloutBuffer.flush``): ONE all-gather of every rank's bytes, for small batches.
 
 One process per GPU (``python -m torch.distributed.run``), ``torch.distributed`` backend ``"nccl"`` (= RCCL on ROCm, over xGMI);
 the CPU tests drive the same code over ``gloo``. Random streams are keyed by GLOBAL env id (``env_id_offset``), so a sharded
@@ -91,7 +97,21 @@ class RolloutBuffer:
         self.storage = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
         self.views = {f.name: self._view(self.storage, f) for f in self.fields}
         self._gathered = None
+        self._mb = {}
         self.t = 0
+        self._check_equal_shards()
+
+    def _check_equal_shards(self) -> None:
+        """all_gather_into_tensor needs the same byte count from every rank: unequal shards (num_envs_global % world_size != 0
+        with ``shard_range``) would hang or fail inside the collective, so they are refused here"""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        on_gpu = dist.get_backend() != 'gloo'
+        n = torch.tensor([self.E, -self.E, self.nbytes, -self.nbytes], dtype=torch.int64, device=self.device if on_gpu else 'cpu')
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        if int(n[0]) != -int(n[1]) or int(n[2]) != -int(n[3]):
+            raise ValueError(f'RolloutBuffer: ranks hold different shard sizes ({-int(n[1])}..{int(n[0])} envs); use a num_envs_global '
+                             'that is a multiple of the world size')
 
     @staticmethod
     def _view(storage: torch.Tensor, f: _Field, lead: tuple = ()) -> torch.Tensor:
@@ -104,6 +124,36 @@ class RolloutBuffer:
     def slot(self, t: int) -> dict[str, torch.Tensor]:
         """Views of time slot ``t`` (contiguous [E_local, ...] tensors a kernel can write into)."""
         return {k: v[t] for k, v in self.views.items()}
+
+    def gather_minibatch(self, num_envs: int, start: int = 0, fields=('observation', 'achieved_goal', 'desired_goal', 'action', 'reward',
+                                                                     'terminated', 'truncated')) -> dict[str, torch.Tensor]:
+        """ONE all-gather of the [T, num_envs, .] slice (local envs start .. start + num_envs) of the named fields: what a learner
+        that samples ``world * num_envs`` envs per update reads. Returns per-field views [world, T, num_envs, ...]."""
+        key = (int(num_envs), tuple(fields))
+        if key not in self._mb:
+            sizes = [int(self.views[f][:, :num_envs].numel() * self.views[f].element_size()) for f in fields]
+            offs = [0]
+            for sz in sizes:
+                offs.append((offs[-1] + sz + 15) // 16 * 16)
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            self._mb[key] = (offs, torch.empty(offs[-1], dtype=torch.uint8, device=self.device),
+                             torch.empty(world * offs[-1], dtype=torch.uint8, device=self.device))
+        offs, send, recv = self._mb[key]
+        for f, o in zip(fields, offs):
+            v = self.views[f][:, start:start + num_envs]
+            send[o:o + v.numel() * v.element_size()].view(v.dtype).view(v.shape).copy_(v)
+        world = 1
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            dist.all_gather_into_tensor(recv, send)
+        else:
+            recv.copy_(send)
+        g = recv.view(world, offs[-1])
+        out = {}
+        for f, o in zip(fields, offs):
+            v = self.views[f][:, :num_envs]
+            out[f] = g[:, o:o + v.numel() * v.element_size()].view(v.dtype).view((world,) + tuple(v.shape))
+        return out
 
     def flush(self) -> dict[str, torch.Tensor]:
         """Single all-gather of the whole buffer over the default process group (no-op gather for one process)."""

@@ -16,10 +16,10 @@ from typing import Any
 import numpy as np
 import torch
 
-from .. import _native
+from .. import _native, spaces
 
 
-class VecBasicPlanarRoboticsEnv:
+class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
     """Batched counterpart of ``BasicPlanarRoboticsEnv`` (BE:21-1626): ``num_envs`` independent copies of one tile /
     mover configuration living on one MI355X.
 
@@ -30,7 +30,10 @@ class VecBasicPlanarRoboticsEnv:
     :param device: a CUDA (ROCm) device; the engine has no CPU path
     """
 
-    metadata = {'render_modes': []}
+    metadata = {'render_modes': [], 'autoreset_mode': 'same_step'}
+    render_mode = None
+    spec = None
+    closed = False
 
     def __init__(
         self,
@@ -232,10 +235,19 @@ class VecBasicPlanarRoboticsEnv:
             _native.check(self._lib.gpr_create(C.byref(cfg), C.byref(handle)))
         self._handle = handle
 
-    def close(self) -> None:
+    def close(self, **kwargs) -> None:
         if getattr(self, '_handle', None) is not None:
             self._lib.gpr_destroy(self._handle)
             self._handle = None
+        self.closed = True
+
+    def render(self):
+        """rendering is out of scope of the GPU engine (render_mode is always None)"""
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
 
     def __del__(self):
         try:

@@ -77,6 +77,7 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         self.v_max, self.a_max, self.j_max, self.threshold_pos = float(v_max), float(a_max), float(j_max), float(threshold_pos)
         self.max_episode_steps, self.autoreset_mode, self.precision = max_episode_steps, autoreset_mode, precision
         self.env_id_offset, self.dtype = int(env_id_offset), _TORCH_DTYPE[precision]
+        self.metadata = dict(self.metadata, autoreset_mode=spaces.autoreset_metadata(autoreset_mode))
 
         # spaces (PU:232-253)
         low_goals = np.zeros(2)

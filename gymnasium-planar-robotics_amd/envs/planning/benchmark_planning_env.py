@@ -101,6 +101,7 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         self.precision = precision
         self.env_id_offset = int(env_id_offset)
         self.dtype = _TORCH_DTYPE[precision]
+        self.metadata = dict(self.metadata, autoreset_mode=spaces.autoreset_metadata(autoreset_mode))
 
         # spaces (PL:242-259); float64 like the reference, whatever the storage precision
         M = self.num_movers

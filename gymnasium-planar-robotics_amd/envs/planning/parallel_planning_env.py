@@ -26,7 +26,7 @@ from ... import _native, spaces
 from .benchmark_planning_env import VecBenchmarkPlanningEnv
 
 
-class VecBenchmarkPlanningParallelEnv:
+class VecBenchmarkPlanningParallelEnv(spaces.ParallelEnvBase):
     metadata = {'name': 'VecBenchmarkPlanningParallelEnv', 'render_modes': []}
 
     def __init__(self, *args, **kwargs) -> None:

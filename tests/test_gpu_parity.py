@@ -428,12 +428,21 @@ def test_parallel_env_agent_views(gpr, M, precision):
     assert penv.agents == [f'mover_{i}' for i in range(M)] and penv.observation_space('mover_0').shape == (4 * M + 2,)
     obs, infos = penv.reset(seed=2)
     g = torch.Generator(device='cuda').manual_seed(0)
-    for step in range(25):
-        act = {a: (torch.rand(E, 2, device='cuda', generator=g) * 20 - 10) for a in penv.agents}
+    n_trunc = 0
+    for step in range(60):  # past the TimeLimit (50): truncated envs are auto-reset in the same call
+        # (the first half of the envs never accelerates: those envs live to the TimeLimit)
+        still = (torch.arange(E, device='cuda') < E // 2).unsqueeze(1)
+        act = {a: (torch.rand(E, 2, device='cuda', generator=g) * 20 - 10).masked_fill(still, 0.0) for a in penv.agents}
         obs, rew, term, trunc, infos = penv.step(act)
         e = penv.env
         v = e._obs['observation'].double().cpu().numpy().reshape(E, M, 2); p = e._obs['achieved_goal'].double().cpu().numpy().reshape(E, M, 2)
         gl = e._obs['desired_goal'].double().cpu().numpy().reshape(E, M, 2); r = e._reward.double().cpu().numpy()
+        # the reward of an env that ended in this call belongs to its TERMINAL state (info['final_obs']), not to the first
+        # observation of the new episode that same-step autoreset returns
+        done = (e._terminated | e._truncated).bool().cpu().numpy()
+        n_trunc += int(e._truncated.sum())
+        fp = e._final['achieved_goal'].double().cpu().numpy().reshape(E, M, 2); fg = e._final['desired_goal'].double().cpu().numpy().reshape(E, M, 2)
+        rp = np.where(done[:, None, None], fp, p); rg = np.where(done[:, None, None], fg, gl)
         tot = np.zeros(E)
         for i, a in enumerate(penv.agents):
             exp = [v[:, i], p[:, i], gl[:, i]]
@@ -444,11 +453,12 @@ def test_parallel_env_agent_views(gpr, M, precision):
             got = obs[a].double().cpu().numpy()
             assert np.abs(got - exp).max() < (1e-12 if precision == 'f64' else 1e-6), (step, a)
             shared = (r == 50) | (r == -50)
-            own = np.where(np.linalg.norm(p[:, i] - gl[:, i], axis=1) <= 0.1, 0.0, -1.0)
+            own = np.where(np.linalg.norm(rp[:, i] - rg[:, i], axis=1) <= 0.1, 0.0, -1.0)
             assert np.array_equal(rew[a].double().cpu().numpy(), np.where(shared, r, own))
             tot += np.where(shared, 0.0, own)
             assert term[a] is term['mover_0'] and torch.equal(term[a], e._terminated.view(torch.bool))
-        assert np.array_equal(tot[~shared], r[~shared])  # the per-agent rewards add up to the env reward (PL:530)
+        assert np.array_equal(tot[~shared], r[~shared])  # the per-agent rewards add up to the env reward (PL:530), truncated envs included
+    assert n_trunc > 0
     assert penv.state().shape == (E, 6 * M)
     penv.close()
 
@@ -507,3 +517,95 @@ def test_full_size_properties(gpr, M, layout_n, E):
     d = (obs['achieved_goal'] - env.pos).flatten().double()
     assert abs(float(d.mean())) < 3e-7 and 0.9e-5 < float(d.std()) < 1.1e-5
     assert float((d.abs() > 3e-5).double().mean()) == pytest.approx(0.0027, abs=0.0015)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# engine additions behind the C ABI: resumable random streams, episode counters, large layouts
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('precision', ['f32', 'f64'])
+def test_checkpoint_restores_bit_exactly(gpr, precision):
+    """state_dict() = the state tensors + gpr_get_rng_state(); a fresh handle that loads it continues the run bit for bit
+    (noise draws, auto-reset samples and all)."""
+    E, M = 2048, 4
+    mk = lambda: gpr.VecBenchmarkPlanningEnv(np.ones((6, 6)), M, num_envs=E, precision=precision)  # noqa: E731
+    a = mk()
+    a.reset(seed=11)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    acts = [(torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10).to(a.dtype) for _ in range(40)]
+    for t in range(20):
+        a.step(acts[t])
+    sd = a.state_dict()
+    assert sd['rng_tick'] == 21 and sd['rng_seed'] == 11  # one reset + 20 steps
+    import io
+    buf = io.BytesIO(); torch.save(sd, buf); buf.seek(0)
+    b = mk()
+    b.load_state_dict(torch.load(buf))
+    for t in range(20, 40):
+        oa, ra, ta, ua, ia = a.step(acts[t])
+        ob, rb, tb, ub, ib = b.step(acts[t])
+        for k in oa:
+            assert torch.equal(oa[k], ob[k]), (t, k)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ua, ub)
+        assert torch.equal(a.pos, b.pos) and torch.equal(a.goals, b.goals) and torch.equal(a.elapsed_steps, b.elapsed_steps)
+    assert int((ta | ua).sum()) >= 0 and a.get_rng_state() == b.get_rng_state() == (11, 41)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize('M,n', [(4, 6), (16, 10)])
+def test_episode_counters_match_the_flags(gpr, M, n):
+    """the on-device counters (per-wavefront popcounts, reduced by gpr_read_counters) equal the sums of the returned flags"""
+    E = 5000
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((n, n)), M, num_envs=E)
+    env.reset(seed=4)
+    env.enable_episode_counters()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    want = np.zeros(6, dtype=np.int64)
+    for t in range(60):
+        a = torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10
+        a[:1000] = 0.0  # (envs that never accelerate live to the TimeLimit)
+        obs, r, term, trunc, info = env.step(a)
+        want += np.array([int((term | trunc).sum()), int(term.sum()), int(trunc.sum()), int(info['is_success'].sum()),
+                          int(info['wall_collision'].sum()), int(info['mover_collision'].sum())])
+        if t == 30:
+            assert np.array_equal(env.read_episode_counters().cpu().numpy(), want)  # totals accumulate across reads
+    assert np.array_equal(env.read_episode_counters().cpu().numpy(), want)
+    assert want[0] > E and want[2] > 0 and want[4] > 0
+    assert np.array_equal(env.all_reduce_episode_counters().cpu().numpy(), want)  # single process: the same numbers
+    env.close()
+
+
+def test_large_layout_tables_fit(gpr, oracle):
+    """a 64 x 64 layout with holes (GPR_MAX_TILES): the f64 tile tables (~47 KB) plus the kernels' static LDS stay launchable, and the
+    verdicts still match the oracle (table bytes vs the 64 KB default LDS limit)"""
+    rng = np.random.default_rng(0)
+    layout = (rng.uniform(size=(64, 64)) > 0.1).astype(np.int8)
+    layout[:8, :8] = 1
+    M, E = 2, 64
+    kw = dict(std_noise=0.0, max_reset_trials=200)
+    env = gpr.VecBenchmarkPlanningEnv(layout, M, num_envs=E, precision='f64', **kw)
+    ref = oracle.OraclePlanningEnv(layout, M, E, **kw)
+    env.reset(seed=1); ref.reset(seed=1)
+    assert np.array_equal(env.pos.cpu().numpy(), ref.pos)
+    a = rng.uniform(-10, 10, size=(E, 2 * M))
+    obs, r, term, trunc, info = env.step(torch.as_tensor(a, device='cuda'))
+    o2 = ref.step(a)
+    assert np.array_equal(term.cpu().numpy(), o2['terminated']) and np.array_equal(info['wall_collision'].cpu().numpy(), o2['wall_collision'])
+    assert np.abs(obs['achieved_goal'].cpu().numpy() - o2['achieved_goal']).max() < 1e-12
+    env.close()
+
+
+def test_bench_two_ranks_on_one_gpu(gpr):
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the two ranks (before touching the GPU), gloo
+    rendezvous on 127.0.0.1, both ranks on cuda:0; rank 0's line carries the weak and the strong shape and the flush extra"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device', '--envs-per-gpu', '4096',
+                        '--steps', '30', '--warmup', '10', '--min-seconds', '0.02', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 30
+    c = line['config']
+    assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 2048
+    assert c['rollout_flush']['env_steps_per_s'] > 0 and 0 < c['done_fraction_per_step'] < 0.5
+    assert c['timed_seconds'] >= 0.02 and c['timed_steps'] % 30 == 0

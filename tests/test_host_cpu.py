@@ -173,6 +173,20 @@ whole = g['reward'].permute(1, 0, 2).reshape(3, 12)
 assert torch.equal(whole, (torch.arange(12, dtype=torch.float32) * 10)[None, :] + torch.arange(3, dtype=torch.float32)[:, None])
 assert torch.equal(g['terminated'].permute(1, 0, 2).reshape(3, 12)[0], (torch.arange(12) % 2).to(torch.uint8))
 assert torch.equal(g['observation'][1, 0, :, 1], torch.arange(6, 12, dtype=torch.float32) + 0.25)
+# a learner-sized minibatch instead of the whole buffer: local envs 1..3 of (reward, terminated) from every rank, ONE all-gather
+mb = buf.gather_minibatch(3, start=1, fields=('reward', 'terminated'))
+assert mb['reward'].shape == (2, 3, 3) and mb['terminated'].dtype == torch.uint8
+for r in range(2):
+    ids = torch.arange(6 * r + 1, 6 * r + 4, dtype=torch.float32)
+    assert torch.equal(mb['reward'][r], ids[None, :] * 10 + torch.arange(3, dtype=torch.float32)[:, None])
+    assert torch.equal(mb['terminated'][r][0], (torch.arange(6 * r + 1, 6 * r + 4) % 2).to(torch.uint8))
+# unequal shards (13 envs over 2 ranks) are refused at construction instead of hanging inside the collective
+s0, s1 = gpr.distributed.shard_range(13, rank, world)
+try:
+    gpr.distributed.RolloutBuffer(3, s1 - s0, 2, 4, dtype=torch.float32, device='cpu')
+    raise SystemExit('unequal shards were accepted')
+except ValueError as e:
+    assert 'different shard sizes' in str(e)
 dist.barrier(); dist.destroy_process_group()
 print('rank', rank, 'ok')
 '''
@@ -275,3 +289,76 @@ def test_pushing_env_host_mirror_and_oracle_actuation(oracle):
         assert err < 1e-12, (i, err)
         n += 1
     assert n == 24
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# optional Gymnasium / PettingZoo binding (gymnasium_planar_robotics/__init__.py:21-41). Neither package exists in this image, so
+# the conditional path is driven with minimal stand-in packages of the same names on sys.path, in a child interpreter.
+# ----------------------------------------------------------------------------------------------------------------------
+_FAKE_GYMNASIUM = {
+    'gymnasium/__init__.py': 'from . import spaces, vector, envs\n',
+    'gymnasium/spaces.py': (
+        'import numpy as np\n'
+        'class Space: pass\n'
+        'class Box(Space):\n'
+        '    def __init__(self, low, high, shape=None, dtype=np.float32):\n'
+        '        shape = np.shape(low) if shape is None else shape\n'
+        '        self.shape, self.dtype = tuple(shape), np.dtype(dtype)\n'
+        '        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self.shape).copy()\n'
+        '        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self.shape).copy()\n'
+        'class Dict(Space, dict):\n'
+        '    def __init__(self, d): dict.__init__(self, d)\n'),
+    'gymnasium/vector.py': (
+        'import enum\n'
+        'class AutoresetMode(enum.Enum):\n'
+        '    NEXT_STEP = "NextStep"; SAME_STEP = "SameStep"; DISABLED = "Disabled"\n'
+        'class VectorEnv:\n'
+        '    metadata = {}\n'),
+    'gymnasium/envs/__init__.py': 'from . import registration\n',
+    'gymnasium/envs/registration.py': (
+        'registry = {}\n'
+        'def register(id, entry_point=None, vector_entry_point=None, max_episode_steps=None, kwargs=None, **kw):\n'
+        '    registry[id] = dict(entry_point=entry_point, vector_entry_point=vector_entry_point, kwargs=kwargs or {})\n'),
+    'pettingzoo/__init__.py': 'class ParallelEnv:\n    pass\n',
+}
+
+
+def test_binds_to_gymnasium_and_pettingzoo_when_importable(tmp_path):
+    for rel, src in _FAKE_GYMNASIUM.items():
+        f = tmp_path / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(src)
+    code = (
+        'import sys, importlib, numpy as np\n'
+        'import gymnasium, pettingzoo\n'
+        'from gymnasium.envs.registration import registry\n'
+        'registry["BenchmarkPushingEnv-v0"] = "someone else (the reference package) registered the bare id first"\n'
+        'import gymnasium_planar_robotics_amd as gpr\n'
+        'assert gpr.spaces.HAVE_GYMNASIUM and gpr.spaces.HAVE_PETTINGZOO\n'
+        'assert set(gpr.registered_ids) == {"gpr_amd/BenchmarkPlanningEnv-v0", "BenchmarkPlanningEnv-v0", "gpr_amd/BenchmarkPushingEnv-v0"}, gpr.registered_ids\n'
+        'assert isinstance(registry["BenchmarkPushingEnv-v0"], str)  # not overwritten\n'
+        'for i in gpr.registered_ids:\n'
+        '    spec = registry[i]; mod, cls = spec["vector_entry_point"].split(":")\n'
+        '    assert spec["kwargs"] == {"max_episode_steps": 50} and spec["entry_point"] is None\n'
+        '    assert hasattr(importlib.import_module(mod), cls)\n'
+        'assert issubclass(gpr.VecBenchmarkPlanningEnv, gymnasium.vector.VectorEnv) and issubclass(gpr.VecBenchmarkPushingEnv, gymnasium.vector.VectorEnv)\n'
+        'assert issubclass(gpr.VecBenchmarkPlanningParallelEnv, pettingzoo.ParallelEnv)\n'
+        'e = gpr.VecBenchmarkPlanningEnv(np.ones((4, 4)), 2, num_envs=8, _host_only=True)\n'
+        '# VectorEnv attribute conformance\n'
+        'assert e.num_envs == 8 and e.render_mode is None and e.closed is False and e.spec is None and e.unwrapped is e\n'
+        'assert isinstance(e.single_observation_space, gymnasium.spaces.Dict) and isinstance(e.single_action_space, gymnasium.spaces.Box)\n'
+        'assert e.observation_space["observation"].shape == (8, 4) and e.action_space.shape == (8, 4) and e.single_action_space.shape == (4,)\n'
+        'assert e.metadata["autoreset_mode"] is gymnasium.vector.AutoresetMode.SAME_STEP\n'
+        'for name in ("reset", "step", "close", "render"): assert callable(getattr(e, name))\n'
+        'e.close(); assert e.closed\n'
+        'print("ok")\n'
+    )
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT, os.environ.get('PYTHONPATH', '')]))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+def test_without_gymnasium_nothing_is_registered():
+    assert gpr.spaces.HAVE_GYMNASIUM is False and gpr.registered_ids == []
+    e = gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 1, num_envs=2, _host_only=True)
+    assert e.metadata['autoreset_mode'] == 'same_step' and e.single_action_space.shape == (2,)
