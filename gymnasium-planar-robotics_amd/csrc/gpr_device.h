@@ -693,7 +693,7 @@ template <typename RT, int LPE, int D> struct PairSweep {
     }
 };
 // Lanes that pad an env group (mover index >= M) are parked at FAR_AWAY so that no live mover ever sees them as a partner.
-template <typename RT> __device__ __forceinline__ RT far_away() { return sizeof(RT) == 8 ? (RT)1e150 : (RT)1e18f; }
+template <typename RT> __device__ __forceinline__ RT far_away() { return (RT)1e18f; }  // (finite as a float too: the parity loop's float pre-tests)
 template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_dist(RT x, RT y) {
     if constexpr (LPE == 1) {
         return Math<RT>::inf();

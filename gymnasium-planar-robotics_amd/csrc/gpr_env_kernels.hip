@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
     const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
-    if constexpr (!FULL || SHAPE == 1) stage_tables(lds, P.tables, P.table_bytes);  // (the box functions read the tables)
+    if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) stage_tables(lds, P.tables, P.table_bytes);  // (the box functions and the literal checks read the tables)
     else __syncthreads();  // (reset_count is initialised)
     const Tables<RT> T = make_tables<RT>(lds, P);
     const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);  // BE:487, add_safety_offset=False
@@ -695,7 +695,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     int vg_rows = 0;
     bool vg_on = true;
     unsigned long long vg_uncovered = ~0ull;
-    for (int cyc = 0; cyc < P.num_cycles; ++cyc) {  // BE:1879
+    // one control cycle of the generic loop in two halves: advance = _mujoco_step_callback (PL:420-450) + mj_step (BE:1882) ...
+    auto advance = [&](int cyc) __attribute__((always_inline)) {
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882)
         if constexpr (Math<RT>::literal) {
             R2<RT> qacc, acc_tmp = a, j1 = a;
@@ -789,16 +790,18 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 p.x = p0.x + dp.x; p.y = p0.y + dp.y;
             }
         }
+    };
+    // ... and checks = BE:1888-1901 on the position pc the cycle ended with: raw per-lane verdicts as wave masks
+    auto checks = [&](int cyc, R2<RT> pc, unsigned long long &wraw, unsigned long long &hraw) __attribute__((always_inline)) {
         // BE:1888-1901: wall check and mover check, each on its own noisy position read. Results are kept as wave masks
         // (one bit per lane, straight out of the vector compares) and restricted to live, unfrozen lanes with scalar ALU ops.
-        unsigned long long wraw, hraw;
         if constexpr (SHAPE == 1) {
-            const Pose<RT> q0{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0};
+            const Pose<RT> q0{pc.x, pc.y, (RT)1, (RT)0, (RT)0, (RT)0};
             if constexpr (NOISE) {
                 bool unc;
                 wraw = __ballot(!pos_valid_box<RT, true>(T, P, q0, bw0, bw1, band_b, &unc));
                 if (eager | ((__ballot(unc) & live_m) != 0ull)) {
-                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                    const Pose<RT> qn = noisy_pose<RT, true>(pc, C.sig_p, key, S * (uint32_t)cyc + 1u);
                     wraw = __ballot(!pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr));
                 }
                 // no partner within the distance pre-filter (BE:411-414) even after two worst-case reads: no collision, no draw
@@ -806,7 +809,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 (void)box_pair_hit<RT, LPE>(q0, c, c1, (RT)2 * band_b, false, &near);
                 hraw = 0ull;
                 if (eager | ((__ballot(near) & live_m) != 0ull)) {
-                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
+                    const Pose<RT> qn = noisy_pose<RT, true>(pc, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
                     hraw = __ballot(box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr));
                 }
             } else {
@@ -815,32 +818,126 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             }
         } else if constexpr (NOISE) {
             bool unc;
-            wraw = __ballot(!pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &unc));
+            wraw = __ballot(!pos_valid_circle<RT, FULL, true>(T, P, pc.x, pc.y, cw_step, C.band_p, &unc));
             if (eager | ((__ballot(unc) & live_m) != 0ull)) {
-                const R2<RT> pw = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u);
+                const R2<RT> pw = noisy<RT, true>(pc, C.sig_p, key, S * (uint32_t)cyc + 1u);
                 wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step));
             }
             hraw = 0ull;
-            if (eager | ((__ballot(pair_min_d2<RT, LPE>(p.x, p.y) <= pair_near2) & live_m) != 0ull)) {  // else: no pair can touch
-                const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
+            if (eager | ((__ballot(pair_min_d2<RT, LPE>(pc.x, pc.y) <= pair_near2) & live_m) != 0ull)) {  // else: no pair can touch
+                const RT md = pair_min_dist<RT, LPE>(pc.x, pc.y);
                 hraw = __ballot(md <= pair_thr);  // BE:409, inclusive
                 if (eager | ((__ballot(absr(md - pair_thr) <= pair_band) & live_m) != 0ull)) {
-                    const R2<RT> pp = noisy<RT, true>(p, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
+                    const R2<RT> pp = noisy<RT, true>(pc, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
                     hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
                 }
             }
         } else {
-            wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, p.x, p.y, cw_step));
+            wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pc.x, pc.y, cw_step));
             hraw = 0ull;
-            if ((__ballot(pair_min_d2<RT, LPE>(p.x, p.y) <= pair_near2) & live_m) != 0ull)
-                hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(p.x, p.y), C.max_csum_step));
+            if ((__ballot(pair_min_d2<RT, LPE>(pc.x, pc.y) <= pair_near2) & live_m) != 0ull)
+                hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pc.x, pc.y), C.max_csum_step));
         }
+    };
+    auto settle = [&](unsigned long long wraw, unsigned long long hraw) {
         // BE:1904-1905: break at the first collision -- the env's state and flags stay those of the colliding cycle.
         // wc_m / mc_m collect the raw per-lane hits of not-yet-frozen envs; only the freeze decision needs the per-env OR now.
         const unsigned long long wb = wraw & live_m & ~frozen_m, mb = hraw & live_m & ~frozen_m;
         wc_m |= wb;
         mc_m |= mb;
-        frozen_m |= group_or<LPE>(wb | mb);
+        const unsigned long long nf = group_or<LPE>(wb | mb);
+        frozen_m |= nf;
+        return nf;
+    };
+    int cyc = 0;
+    if constexpr (Math<RT>::literal && FULL && SHAPE == 0 && !JERK) {
+        // PARITY MODE ON A GRID WITHOUT HOLES: the reference's arithmetic, but its checks only where they can matter. The state
+        // advances in double exactly as above (v += dt a; p += dt v, the same operations in the same order). Whether a cycle
+        // needs the literal wall / pair checks at all is decided in FLOAT on a float copy of the position: on a full grid with
+        // circles smaller than half a tile, BE:459-788 is "the circle's bounding box lies strictly inside the grid" (DESIGN.md:
+        // interior tile edges never invalidate), so a position further from the four outer limits and from every other mover
+        // than noise band + float slack is valid for every possible read, and the literal tests -- table look-ups, tile-edge
+        // uncertainty, double-precision Box-Muller draws -- are evaluated only in the flagged cycles, on the double state saved
+        // for them. Blocks of KB cycles, one decision per block, as in the throughput loop; cycles in which a lane may reach
+        // the speed limit go through advance() one by one (its clamp is a sqrt and four divisions in double).
+        constexpr int KB = 4;
+        const float INFf = __builtin_huge_valf();
+        const float cxf = (float)((RT)0.5 * (C.gx0 + C.gx1)), cyf = (float)((RT)0.5 * (C.gy0 + C.gy1));
+        const float kwf = (float)(cw_step.wx - cw_step.wy);
+        float w0f = eager ? -INFf : (float)(cw_step.wx - C.band_p) - 4e-6f;                  // surely valid iff reach < w0f
+        const float pbf = (float)(C.max_csum_step + band_pair) + 8e-6f;
+        float p0f = eager ? INFf : pbf * pbf * 1.00001f;                                     // surely no hit iff d2 > p0f
+        // clamp rungs (double): the squared speed |v + dt a|^2 below which a lane stays outside the clamp band for k more cycles
+        const R2<RT> dta_d{C.dt * a.x, C.dt * a.y};
+        const RT adt = sqrt(dta_d.x * dta_d.x + dta_d.y * dta_d.y) * (RT)1.000001 + (RT)1e-12;
+        const RT vl = (C.v_max - C.band_v) * (RT)0.999999;
+        auto rung = [&](int k) { const RT m = vl - (RT)k * adt; return m > (RT)0 ? m * m : (RT)-1; };
+        RT r1 = eager ? (RT)-1 : rung(KB - 1), r2 = eager ? (RT)-1 : rung(3 * KB - 1), r3 = eager ? (RT)-1 : rung(P.num_cycles - 1);
+        auto lane_out = [&]() { w0f = INFf; p0f = -1.f; r1 = r2 = r3 = Math<RT>::inf(); };
+        if (!live | lane_of(frozen_m)) lane_out();
+        int next_c = 0;
+        auto reaches = [&](R2<RT> pc, float &e, float &m) {
+            const float qx = (float)pc.x - cxf, qy = (float)pc.y - cyf;
+            e = __builtin_fmaxf(__builtin_fabsf(qx), __builtin_fabsf(qy) + kwf);
+            m = INFf;
+            if constexpr (LPE > 1) m = pair_min_dist<float, LPE>(qx, qy);
+        };
+        auto literal_cycle = [&](int c, R2<RT> pc, R2<RT> vc) {  // the literal checks of cycle c on its saved state
+            unsigned long long wraw, hraw;
+            checks(c, pc, wraw, hraw);
+            const unsigned long long nf = settle(wraw, hraw);
+            if (nf != 0ull) {
+                if (lane_of(nf)) { p = pc; v = vc; lane_out(); }
+            }
+        };
+        while (cyc + KB <= P.num_cycles) {
+            if (cyc + KB - 1 >= next_c) {
+                const RT t0 = v.x + dta_d.x, t1 = v.y + dta_d.y, n2 = t0 * t0 + t1 * t1;
+                if (__ballot(!(n2 < r1)) != 0ull) {
+                    // some lane may clamp within this block: its cycles one by one (advance() decides about readings and clamp)
+                    for (int j = 0; j < KB; ++j, ++cyc) {
+                        advance(cyc);
+                        float e, m;
+                        reaches(p, e, m);
+                        if ((__ballot(!(e < w0f)) | __ballot(m <= p0f)) != 0ull) literal_cycle(cyc, p, v);
+                    }
+                    continue;
+                }
+                next_c = cyc + 1 + (__ballot(!(n2 < r2)) != 0ull ? KB - 1 : __ballot(!(n2 < r3)) != 0ull ? 3 * KB - 1 : P.num_cycles - 1);
+            }
+            // a quiet block: qacc = a in every cycle (PL:636-637)
+            const R2<RT> vb = v;
+            R2<RT> ps[KB];
+            float es[KB], ms[KB], eacc = -INFf, macc = INFf;
+            const bool moving = !lane_of(frozen_m);
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                if (moving) {
+                    v.x = v.x + dta_d.x; v.y = v.y + dta_d.y;
+                    p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
+                }
+                ps[j] = p;
+                reaches(p, es[j], ms[j]);
+                eacc = __builtin_fmaxf(eacc, es[j]); macc = __builtin_fminf(macc, ms[j]);
+            }
+            if (moving) acc = a;
+            if ((__ballot(!(eacc < w0f)) | __ballot(macc <= p0f)) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    if ((__ballot(!(es[j] < w0f)) | __ballot(ms[j] <= p0f)) == 0ull) continue;
+                    R2<RT> vj = vb;  // the velocity cycle j ended with: the same j + 1 additions again
+                    for (int i = 0; i <= j; ++i) { vj.x = vj.x + dta_d.x; vj.y = vj.y + dta_d.y; }
+                    literal_cycle(cyc + j, ps[j], vj);
+                }
+            }
+            cyc += KB;
+        }
+    }
+    for (; cyc < P.num_cycles; ++cyc) {  // BE:1879
+        advance(cyc);
+        unsigned long long wraw, hraw;
+        checks(cyc, p, wraw, hraw);
+        (void)settle(wraw, hraw);
     }
     }
     wc_m = group_or<LPE>(wc_m);
@@ -977,7 +1074,7 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc], c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];
     R2<RT> p = load2<ST, RT>(P.pos, idx), g = load2<ST, RT>(P.goal, idx);
     if (mv >= M) p.x = p.y = far_away<RT>();
-    if constexpr (!FULL || SHAPE == 1) stage_tables(lds, P.tables, P.table_bytes);
+    if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
     Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, 1, p, g, wc, mc);
@@ -999,7 +1096,7 @@ template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, i
 static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) {
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
-    const unsigned lds = (FULL && SHAPE == 0) ? 0u : P.table_bytes;
+    const unsigned lds = (FULL && SHAPE == 0 && !Math<RT>::literal) ? 0u : P.table_bytes;
     // the tile tables of a large layout (64 x 64 cells in f64: 47 KB) plus the kernels' static LDS exceed the 64 KB a launch
     // gets by default: raise the kernel's limit once (gfx950 has 160 KB per CU; gpr_create bounds the table size)
     if (lds > 32u * 1024u) {
@@ -1027,9 +1124,10 @@ template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipEr
         }
         return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 1>(is_reset, P, s);
     }
-    // the throughput-mode wall check has a table-free form for grids without holes (pos_valid_circle): separate kernels
-    if constexpr (!Math<RT>::literal) {
-        if (P.layout_full) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 0>(is_reset, P, s);
+    // grids without holes: the throughput-mode wall check has a table-free form (pos_valid_circle), and the parity-mode step
+    // loop evaluates its literal checks only near the outer walls (acceleration actions): separate kernels
+    if constexpr (!Math<RT>::literal || !JERK) {
+        if (P.layout_full && (!Math<RT>::literal || !is_reset)) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 0>(is_reset, P, s);
     }
     return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 0>(is_reset, P, s);
 }
