@@ -990,7 +990,10 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     // its cycles: the envs the slowest wavefront queues while it is still cycling are then reset before it is done, and
     // nothing but its own last-minute entries is left for the end. Every wavefront gets here without waiting for anything, so
     // the wait ends.
-    constexpr int EPW = 64 / LPE;  // envs per claim
+    // envs per claim. Wide env groups reject most candidates (PL:381-383 on all movers at once: ~45 trials per reset with 16
+    // movers), so their claims stay small enough for every env to get at least four parallel trial slots
+    constexpr int EPW = LPE >= 8 ? (64 / LPE >= 4 ? 64 / LPE / 4 : 1) : 64 / LPE;
+    constexpr int GROUPS = 64 / LPE;
     GPR_WT(const long long wt1 = __builtin_amdgcn_s_memtime();)
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
@@ -1016,7 +1019,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         GPR_WT(wt_served += n;)
         // S lane groups per claimed env: the largest power of two with n * S <= 64 / LPE
         int S = 1;
-        while (2 * S * n <= EPW) S *= 2;
+        while (2 * S * n <= GROUPS) S *= 2;
         const int gi = (int)(threadIdx.x & 63) / LPE;
         const int eslot = gi / S;
         const bool have = eslot < n;
