@@ -253,17 +253,21 @@ template <typename RT> void fill_push(const gpr_env &e, const gpr_push_params &p
     q.mu = (RT)pp.friction_contact; q.tc = (RT)pp.contact_timeconst;
     q.obj_noise = (RT)pp.object_noise; q.min_mo_dist = (RT)pp.min_mo_dist;
     q.omin_x = (RT)pp.obj_min_xy[0]; q.omin_y = (RT)pp.obj_min_xy[1]; q.omax_x = (RT)pp.obj_max_xy[0]; q.omax_y = (RT)pp.obj_max_xy[1];
+    const double reach = std::sqrt(ax * ax + ay * ay) + h * std::sqrt(2.0);
+    q.reach2 = (RT)(reach * reach);
 }
 
-int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s) {
+int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, const void *opt_start = nullptr, const void *opt_goal = nullptr) {
     hipError_t he;
+    PushPtrs X = env->push_ptrs;
+    X.opt_start = opt_start; X.opt_goal = opt_goal;
     switch (env->cfg.precision) {
         case GPR_PRECISION_F32:
-            he = env->cfg.learn_jerk ? launch_push<float, double>(is_reset, P, env->push_d, env->push_ptrs, s)
-                                     : launch_push<float, float>(is_reset, P, env->push_f, env->push_ptrs, s);
+            he = env->cfg.learn_jerk ? launch_push<float, double>(is_reset, P, env->push_d, X, s)
+                                     : launch_push<float, float>(is_reset, P, env->push_f, X, s);
             break;
-        case GPR_PRECISION_F32_F64ACC: he = launch_push<float, double>(is_reset, P, env->push_d, env->push_ptrs, s); break;
-        default: he = launch_push<double, double>(is_reset, P, env->push_d, env->push_ptrs, s); break;
+        case GPR_PRECISION_F32_F64ACC: he = launch_push<float, double>(is_reset, P, env->push_d, X, s); break;
+        default: he = launch_push<double, double>(is_reset, P, env->push_d, X, s); break;
     }
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, is_reset ? "push reset kernel launch" : "push step kernel launch");
 }
@@ -483,29 +487,35 @@ int gpr_agent_views(gpr_env *env, const gpr_step_out *out, void *agent_obs_dev, 
 
 int gpr_push_configure(gpr_env *env, const gpr_push_params *pp, const gpr_push_state *st) {
     if (!env || !pp || !st) return fail(env, GPR_E_INVALID, "gpr_push_configure: NULL argument");
-    if (env->cfg.num_movers != 1 || env->cfg.c_shape != GPR_SHAPE_CIRCLE)
-        return fail(env, GPR_E_INVALID, "gpr_push_configure: BenchmarkPushingEnv has one mover with a circular collision shape (PU:195-196)");
+    if (env->cfg.num_movers < 1 || env->cfg.num_movers > 2 || env->cfg.c_shape != GPR_SHAPE_CIRCLE)
+        return fail(env, GPR_E_INVALID, "gpr_push_configure: BenchmarkPushingEnv has one mover (PU:195-196; the engine also offers two) with a "
+                                        "circular collision shape");
     if (!(pp->mover_mass > 0) || !(pp->object_mass > 0) || !(pp->object_half_size > 0) || !(pp->mover_half_size[0] > 0) ||
         !(pp->mover_half_size[1] > 0) || !(pp->contact_timeconst > 0) || !(pp->object_damping >= 0) || !(pp->gravity >= 0))
         return fail(env, GPR_E_INVALID, "gpr_push_configure: masses, sizes and the contact time constant must be positive");
     if (!st->mover_rot_dev || !st->object_dev) return fail(env, GPR_E_INVALID, "gpr_push_configure: state pointers must be set");
     fill_push<float>(*env, *pp, env->push_f);
     fill_push<double>(*env, *pp, env->push_d);
-    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev};
+    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev, nullptr, nullptr};
     env->push_ready = true;
     return GPR_OK;
 }
 
-int gpr_push_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {
+int gpr_push_reset_opts(gpr_env *env, const uint8_t *mask_dev, const void *mover_start_xy_dev, const void *object_goal_xy_dev,
+                        const gpr_step_out *out, void *hip_stream) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_push_reset: NULL handle");
     if (!env->bound || !env->push_ready) return fail(env, GPR_E_UNBOUND, "gpr_push_reset: call gpr_bind_state and gpr_push_configure first");
     int rc = check_out(env, out);
     if (rc != GPR_OK) return rc;
     KParams P = make_params(env, out, false);
     P.mask = mask_dev;
-    rc = push_launch(env, true, P, as_stream(hip_stream));
+    rc = push_launch(env, true, P, as_stream(hip_stream), mover_start_xy_dev, object_goal_xy_dev);
     if (rc == GPR_OK) env->tick += 1;
     return rc;
+}
+
+int gpr_push_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {
+    return gpr_push_reset_opts(env, mask_dev, nullptr, nullptr, out, hip_stream);
 }
 
 int gpr_push_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream) {

@@ -65,9 +65,11 @@ template <typename RT> struct PushCst {
     RT fric_dv, fric_dw;                // velocity lost per cycle to tile friction: mu g dt, torsional
     RT mu, tc;                          // contact friction, contact time constant (penetration recovery)
     RT obj_noise, min_mo_dist, omin_x, omin_y, omax_x, omax_y;
+    RT reach2;                          // (circumradius of a mover + circumradius of the object)^2: the contact broad phase
 };
 struct PushPtrs {
     void *mover_rot, *object;
+    const void *opt_start, *opt_goal;   // reset options 'mover_start_xy_pos' [E][2 NM] / 'object_goal_xy_pos' [E][2] (PU:389-391, 412-414), nullable
 };
 template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
 template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }

@@ -1,5 +1,5 @@
 """``VecBenchmarkPushingEnv``: ``num_envs`` copies of the reference's ``BenchmarkPushingEnv`` (one mover pushes one box over 3x3
-tiles), one fused HIP kernel launch per ``step()``.
+tiles; ``num_movers=2`` is the engine's own two-mover variant, BASELINE.json's config 3), one fused HIP kernel launch per ``step()``.
 
 Reference: gymnasium_planar_robotics/envs/manipulation/benchmark_pushing_env.py (PU:line). Same constructor keywords, observation
 dict (``observation`` = mover position and velocity (and acceleration with ``learn_jerk``), ``achieved_goal`` = object position,
@@ -10,9 +10,16 @@ and TimeLimit (50) as the registered ``BenchmarkPushingEnv-v0``.
 termination / info rules, the reset sampling rules, the wall check. **Not pinned**: contact. The reference hands mover-object and
 object-tile contact, friction and the soft impedance hold of the mover's orientation to MuJoCo; MuJoCo is not available to this
 build and no reference test exercises contact. The kernels therefore integrate the engine's own planar rigid-body model
-``gpr-push-v1`` (include/gpr.h): 3-DoF boxes, separating-axis contact, sequential impulses with Coulomb friction and a
-20 ms penetration-recovery time constant, Coulomb + torsional friction against the tiles, the reference's joint damping and
-impedance gains on the yaw. It is MuJoCo-like in its parameters, not MuJoCo-equal in its trajectories.
+``gpr-push-v2`` (include/gpr.h): 3-DoF boxes, separating-axis contact with at most four points per pair,
+sequential impulses with Coulomb friction and a 20 ms penetration-recovery time constant, Coulomb + torsional friction against the
+tiles, the reference's joint damping and impedance gains on the yaw. It is MuJoCo-like in its parameters, not MuJoCo-equal in its
+trajectories.
+
+**Two movers** (``num_movers=2``; the reference hard-codes one, PU:196): both movers are actuated (action ``(num_envs, 4)``) and
+push the same object; the observation keeps the reference's ``concatenate((pos, vel[, acc]), axis=0).flatten()`` = all positions,
+all velocities[, all accelerations] (PU:540-545); the movers do not touch each other -- their collision circles meeting ends the
+episode like a wall collision (reward -50, ``info['mover_collision']``), the planning env's rule (BE:355-424); a reset re-draws the
+two starts together until the circles (with the safety offset) are apart, and the object keeps ``min_mo_dist`` from both.
 """
 from __future__ import annotations
 
@@ -58,7 +65,9 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         precision: str = 'f32',
         env_id_offset: int = 0,
         max_reset_trials: int = 10000,
+        num_movers: int = 1,
         _host_only: bool = False,
+        _push_overrides: dict[str, float] | None = None,
     ) -> None:
         if render_every_cycle or use_mj_passive_viewer:
             raise ValueError('rendering is out of scope of the GPU engine')
@@ -69,7 +78,8 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         self.object_mass = 0.01
         self.object_noise_xy_pos = 1e-5
         self.idx_mover = 0
-        super().__init__(layout_tiles=np.ones((3, 3)), num_movers=1, num_envs=num_envs, tile_params=None, mover_params=mover_params,
+        assert num_movers in (1, 2), 'the pushing env has one mover (PU:196) or, as an engine extension, two'
+        super().__init__(layout_tiles=np.ones((3, 3)), num_movers=num_movers, num_envs=num_envs, tile_params=None, mover_params=mover_params,
                          initial_mover_zpos=initial_mover_zpos, std_noise=std_noise, render_mode=render_mode,
                          collision_params=collision_params, device=device, _host_only=_host_only)  # PU:195-196
         assert self.c_shape == 'circle', "the GPU pushing env supports the default 'circle' collision shape"
@@ -82,14 +92,15 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         # spaces (PU:232-253)
         low_goals = np.zeros(2)
         high_goals = np.array([np.max(self.x_pos_tiles) + (self.tile_size[0] / 2), np.max(self.y_pos_tiles) + (self.tile_size[1] / 2)])
-        self.obs_dim = (2 + int(self.learn_jerk)) * 2
+        NM = self.num_movers
+        self.obs_dim = (2 + int(self.learn_jerk)) * 2 * NM
         self.single_observation_space = spaces.Dict({
             'observation': spaces.Box(low=-np.inf, high=np.inf, shape=(self.obs_dim,), dtype=np.float64),
             'achieved_goal': spaces.Box(low=low_goals, high=high_goals, dtype=np.float64),
             'desired_goal': spaces.Box(low=low_goals, high=high_goals, dtype=np.float64),
         })
         lim = self.j_max if self.learn_jerk else self.a_max
-        self.single_action_space = spaces.Box(low=-lim, high=lim, shape=(2,), dtype=np.float64)
+        self.single_action_space = spaces.Box(low=-lim, high=lim, shape=(2 * NM,), dtype=np.float64)
         self.observation_space = spaces.Dict({k: spaces.batch_box(v, self.num_envs) for k, v in self.single_observation_space.items()})
         self.action_space = spaces.batch_box(self.single_action_space, self.num_envs)
 
@@ -110,8 +121,8 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
                             max_xy_pos=self.max_xy_pos, min_goal_dist=0.0, max_reset_trials=max_reset_trials, precision=precision)
         E, dev, dt = self.num_envs, self.device, self.dtype
         z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
-        self.pos, self.vel, self.acc, self.goals = z(E, 2), z(E, 2), z(E, 2), z(E, 2)  # mover x,y state; object goal
-        self.mover_rot = z(E, 2)   # mover yaw, yaw rate
+        self.pos, self.vel, self.acc, self.goals = z(E, 2 * NM), z(E, 2 * NM), z(E, 2 * NM), z(E, 2)  # mover x,y state; object goal
+        self.mover_rot = z(E, 2 * NM)   # (yaw, yaw rate) per mover
         self.object = z(E, 6)      # object x, y, yaw, vx, vy, yaw rate
         self.elapsed_steps = z(E, dtype=torch.int32)
         self._obs = OrderedDict(observation=z(E, self.obs_dim), achieved_goal=z(E, 2), desired_goal=z(E, 2))
@@ -129,6 +140,8 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
             9.81, 0.1,        # gravity; impedance rotational stiffness (PU:266)
             0.02,             # MuJoCo default solref time constant
             self.object_noise_xy_pos, self.min_mo_dist, (C.c_double * 2)(*self.object_min_xy_pos), (C.c_double * 2)(*self.object_max_xy_pos))
+        for k, v in (_push_overrides or {}).items():  # (tests of the contact model's invariants switch friction / damping off)
+            setattr(self._push_params, k, v)
         pstate = _native.GprPushState(self.mover_rot.data_ptr(), self.object.data_ptr())
         _native.check(self._lib.gpr_push_configure(self._handle, C.byref(self._push_params), C.byref(pstate)), self._handle)
         use_final = autoreset_mode == 'same_step'
@@ -144,26 +157,47 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         return {'is_success': self._is_success.view(torch.bool), 'mover_collision': self._mover_collision.view(torch.bool),
                 'wall_collision': self._wall_collision.view(torch.bool)}
 
+    def _state_tensors(self) -> dict[str, torch.Tensor]:
+        return {'pos': self.pos, 'vel': self.vel, 'acc': self.acc, 'goals': self.goals, 'mover_rot': self.mover_rot, 'object': self.object,
+                'elapsed_steps': self.elapsed_steps}
+
+    supports_two_movers = True
+
     def reset(self, seed: int | None = None, options: dict[str, Any] | None = None):
-        """PU:373-417 + BE:1770-1833. ``options={'mask': bool tensor}`` resets a subset (the reference's fixed-position options
-        ``mover_start_xy_pos`` / ``object_goal_xy_pos`` can be emulated by writing ``pos`` / ``goals`` after the reset)."""
+        """PU:373-417 + BE:1770-1833. ``options``: ``'mask'`` (bool tensor) resets a subset; the reference's
+        ``'mover_start_xy_pos'`` ((num_movers, 2), or batched (num_envs, num_movers, 2)) fixes the mover start(s) -- the object's start
+        is still rejection-sampled to keep ``min_mo_dist`` from it (PU:396-407) -- and ``'object_goal_xy_pos'`` ((2,) or
+        (num_envs, 2)) fixes the goal (PU:389-391, 412-414)."""
         if seed is not None or self._needs_seed:
             _native.check(self._lib.gpr_seed(self._handle, int(seed if seed is not None else np.random.SeedSequence().entropy % (1 << 63))),
                           self._handle)
             self._needs_seed = False
+        options = options or {}
         mask = None
-        if options is not None and options.get('mask') is not None:
+        if options.get('mask') is not None:
             mask = torch.as_tensor(options['mask'], device=self.device).to(torch.uint8).contiguous()
+
+        def fixed(key, width):
+            if options.get(key) is None:
+                return None
+            t = torch.as_tensor(np.asarray(options[key], dtype=np.float64) if not isinstance(options[key], torch.Tensor) else options[key],
+                                device=self.device).to(self.dtype).reshape(-1, width)
+            assert t.shape[0] in (1, self.num_envs), f'options[{key!r}] must hold one value or one per env'
+            return t.expand(self.num_envs, width).contiguous()
+
+        start, goal = fixed('mover_start_xy_pos', 2 * self.num_movers), fixed('object_goal_xy_pos', 2)
         with torch.cuda.device(self.device):
-            _native.check(self._lib.gpr_push_reset(self._handle, mask.data_ptr() if mask is not None else None, C.byref(self._out),
-                                                   self._stream()), self._handle)
+            _native.check(self._lib.gpr_push_reset_opts(self._handle, mask.data_ptr() if mask is not None else None,
+                                                        start.data_ptr() if start is not None else None,
+                                                        goal.data_ptr() if goal is not None else None, C.byref(self._out), self._stream()),
+                          self._handle)
         return OrderedDict(self._obs), self._info_dict()
 
     def step(self, action: torch.Tensor):
-        """BE:1835-1950 with the callbacks of PU:419-607; action (num_envs, 2): mover acceleration (or jerk)."""
+        """BE:1835-1950 with the callbacks of PU:419-607; action (num_envs, 2 * num_movers): mover acceleration(s) (or jerk(s))."""
         if not isinstance(action, torch.Tensor):
             action = torch.as_tensor(np.asarray(action), device=self.device)
-        assert tuple(action.shape) == (self.num_envs, 2), 'action dim != action_space dim'
+        assert tuple(action.shape) == (self.num_envs, 2 * self.num_movers), 'action dim != action_space dim'
         if action.dtype != self.dtype or action.device != self.device or not action.is_contiguous():
             action = action.to(device=self.device, dtype=self.dtype).contiguous()
         with torch.cuda.device(self.device):
@@ -178,6 +212,8 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         ag = torch.as_tensor(achieved_goal, device=self.device).reshape(-1, 2).double()
         dg = torch.as_tensor(desired_goal, device=self.device).reshape(-1, 2).double()
         wc = torch.as_tensor(info['wall_collision'], device=self.device).reshape(-1).bool()
+        if info.get('mover_collision') is not None:  # (two movers)
+            wc = wc | torch.as_tensor(info['mover_collision'], device=self.device).reshape(-1).bool()
         reached = (ag - dg).norm(dim=1) <= self.threshold_pos
         r = torch.where(wc, torch.full_like(reached, -50.0, dtype=torch.float64), torch.full_like(reached, -1.0, dtype=torch.float64))
         return torch.where(reached & ~wc, torch.zeros_like(r), r).to(self.dtype)

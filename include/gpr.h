@@ -160,12 +160,14 @@ int gpr_agent_views(gpr_env *env, const gpr_step_out *out, void *agent_obs_dev, 
 
 /* ---- BenchmarkPushingEnv (gymnasium_planar_robotics/envs/manipulation/benchmark_pushing_env.py, "PU") -----------------
  * One mover pushes one box over 3x3 tiles. The handle is created by gpr_create with num_movers = 1, a 3x3 layout and the
- * 'circle' collision shape (PU:195-196); gpr_push_configure adds the object. Pinned by the reference: mover control and
- * clamping (PU:419-448), observation / reward / terminated / info (PU:457-607), reset sampling (PU:373-417), wall check.
- * NOT pinned ("parity unpinned"): contact dynamics -- the reference delegates them to MuJoCo, which this pipeline cannot
- * run and which no reference test exercises; the kernels integrate the engine's own planar rigid-body model gpr-push-v1
- * (DESIGN.md): 3-DoF boxes, SAT contact, sequential impulses with Coulomb friction, tile friction, joint damping (PU:335),
- * impedance hold of the mover's yaw (PU:261-267). */
+ * 'circle' collision shape (PU:195-196); gpr_push_configure adds the object. num_movers = 2 is the engine's extension to
+ * BASELINE.json's "2 movers + 1 pushed object": both movers push the object, the two movers ending the episode like a wall
+ * collision when their collision circles meet (the planning env's rule, BE:355-424); every per-mover array doubles.
+ * Pinned by the reference: mover control and clamping (PU:419-448), observation / reward / terminated / info (PU:457-607), reset
+ * sampling (PU:373-417), wall check. NOT pinned ("parity unpinned"): contact dynamics -- the reference delegates them to MuJoCo,
+ * which this pipeline cannot run and which no reference test exercises; the kernels integrate the engine's own planar
+ * rigid-body model gpr-push-v2: 3-DoF boxes, SAT contact with at most four points per pair, sequential
+ * impulses with Coulomb friction, tile friction, joint damping (PU:335), impedance hold of the movers' yaw (PU:261-267). */
 typedef struct {
     double mover_mass;          /* mover_params['mass'] (BE:230) */
     double mover_half_size[2];  /* mover_params['size'][:2] (BE:250) */
@@ -181,17 +183,22 @@ typedef struct {
     double obj_min_xy[2], obj_max_xy[2]; /* PU:257-258 */
 } gpr_push_params;
 
-/* extra state, DEVICE: mover_rot [E][2] = (yaw, yaw rate); object [E][6] = (x, y, yaw, vx, vy, yaw rate). gpr_state.goal_dev holds
- * the object's goal [E][2]; pos / vel / acc are the mover's [E][2]. */
+/* extra state, DEVICE (NM = num_movers): mover_rot [E][2 NM] = (yaw, yaw rate) per mover; object [E][6] = (x, y, yaw, vx, vy, yaw
+ * rate). gpr_state.goal_dev holds the object's goal [E][2]; pos / vel / acc are the movers' [E][2 NM]. */
 typedef struct {
     void *mover_rot_dev;
     void *object_dev;
 } gpr_push_state;
 
 int gpr_push_configure(gpr_env *env, const gpr_push_params *params, const gpr_push_state *state);
-/* reset() / step() of BenchmarkPushingEnv; out.observation_dev is [E][4] (mover position, velocity) or [E][6] (+ acceleration,
- * PU:556-559), achieved_goal / desired_goal are [E][2] (PU:564-568). */
+/* reset() / step() of BenchmarkPushingEnv; out.observation_dev is [E][4 NM] (all mover positions, all velocities) or [E][6 NM] (+ all
+ * accelerations, PU:540-545), achieved_goal / desired_goal are [E][2] (PU:564-568); action_dev is [E][2 NM]. */
 int gpr_push_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream);
+/* ... with the reset options of PU:389-391 / PU:412-414: mover_start_xy_dev [E][2 NM] real replaces the sampled mover start(s)
+ * ('mover_start_xy_pos'), object_goal_xy_dev [E][2] real the sampled goal ('object_goal_xy_pos'); either may be NULL. The object's
+ * start is still rejection-sampled against min_mo_dist from the given mover position(s), as PU:396-407 does. */
+int gpr_push_reset_opts(gpr_env *env, const uint8_t *mask_dev, const void *mover_start_xy_dev, const void *object_goal_xy_dev,
+                        const gpr_step_out *out, void *hip_stream);
 int gpr_push_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
 
 /* ---- stateless operators (f64, device pointers) --------------------------------------------------------------- */

@@ -803,9 +803,23 @@ typedef struct { double x, y, th, vx, vy, w; } body2;
 
 static double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
 
-/* One control cycle of the two planar bodies. u = commanded mover acceleration (world x,y). Semi-implicit Euler:
- * velocities first (external forces, then contact impulses), then positions with the new velocities. */
-static void push_cycle(const gpro_env_cfg *cfg, const gpro_push_params *pp, body2 *m, body2 *o, double ux, double uy) {
+/* One control cycle of nm (1 or 2) movers and the object, model "gpr-push-v2". u[i] = commanded acceleration of mover i (world
+ * x,y). Semi-implicit Euler: velocities first (external forces, then contact impulses), then positions with the new velocities.
+ * Contacts: mover i <-> object for every mover (the movers do not touch each other: coming within their collision circles
+ * ends the episode, as in the planning env). Per pair: broad phase on the circumradii, separating-axis test over the 4 face
+ * normals, at most GPRO_PUSH_SLOTS contact points (the first vertices, in the fixed order object vertices 0..3 then mover
+ * vertices 0..3, that lie inside the other box), effective masses inverted once; then 4 sweeps of sequential impulses over
+ * mover 0's points, mover 1's points. */
+#define GPRO_PUSH_SLOTS 4
+typedef struct {
+    int np;
+    double nx, ny;
+    double rmx[GPRO_PUSH_SLOTS], rmy[GPRO_PUSH_SLOTS], rox[GPRO_PUSH_SLOTS], roy[GPRO_PUSH_SLOTS];
+    double rmn[GPRO_PUSH_SLOTS], ron[GPRO_PUSH_SLOTS], rmt[GPRO_PUSH_SLOTS], rot_[GPRO_PUSH_SLOTS];
+    double inv_kn[GPRO_PUSH_SLOTS], inv_kt[GPRO_PUSH_SLOTS], bias[GPRO_PUSH_SLOTS], jn[GPRO_PUSH_SLOTS], jt[GPRO_PUSH_SLOTS];
+} push_pair;
+
+static void push_cycle(const gpro_env_cfg *cfg, const gpro_push_params *pp, int nm, body2 *mv, body2 *o, const double (*u)[2]) {
     const double dt = cfg->dt;
     const double ax = pp->mover_half[0], ay = pp->mover_half[1], h = pp->object_half;
     const double Im = pp->mover_mass * (ax * ax + ay * ay) / 3.0, Io = pp->object_mass * (2.0 * h * h) / 3.0;
@@ -813,9 +827,12 @@ static void push_cycle(const gpro_env_cfg *cfg, const gpro_push_params *pp, body
     /* 1. external forces. mover: actuator force m*u (PU:305-319); yaw held by the impedance law tau = K(0 - th) - D w with
      * D = 2 sqrt(K m) (IMP:42-47, PU:261-267), damping treated implicitly. */
     const double Kr = pp->rot_stiffness, Dr = 2.0 * sqrt(Kr * pp->mover_mass);
-    m->vx = m->vx + dt * ux;
-    m->vy = m->vy + dt * uy;
-    m->w = (m->w + dt * (Kr * (0.0 - m->th)) * inv_Im) / (1.0 + dt * Dr * inv_Im);
+    for (int i = 0; i < nm; ++i) {
+        body2 *m = mv + i;
+        m->vx = m->vx + dt * u[i][0];
+        m->vy = m->vy + dt * u[i][1];
+        m->w = (m->w + dt * (Kr * (0.0 - m->th)) * inv_Im) / (1.0 + dt * Dr * inv_Im);
+    }
     /* object: free-joint damping (PU:335, implicit like MuJoCo's Euler integrator), then Coulomb friction with the tile,
      * never reversing the motion */
     double s = 1.0 / (1.0 + dt * pp->object_damping * inv_mo);
@@ -827,143 +844,199 @@ static void push_cycle(const gpro_env_cfg *cfg, const gpro_push_params *pp, body
         double dw = pp->friction_torsional * pp->object_mass * pp->gravity * inv_Io * dt, aw = fabs(o->w);
         if (aw <= dw) o->w = 0.0; else o->w = o->w * ((aw - dw) / aw);
     }
-    /* 2. contact mover box <-> object box: separating-axis test over the 4 face normals */
-    const double cm = cos(m->th), sm = sin(m->th), co = cos(o->th), so = sin(o->th);
-    const double axes[4][2] = {{cm, sm}, {-sm, cm}, {co, so}, {-so, co}};
-    const double dx = o->x - m->x, dy = o->y - m->y;
-    double best = INFINITY, nx = 0.0, ny = 0.0;
-    int touching = 1;
-    for (int k = 0; k < 4; ++k) {
-        const double ex = axes[k][0], ey = axes[k][1];
-        const double rm = ax * fabs(ex * cm + ey * sm) + ay * fabs(-ex * sm + ey * cm);
-        const double ro = h * fabs(ex * co + ey * so) + h * fabs(-ex * so + ey * co);
-        const double d = dx * ex + dy * ey;
-        const double overlap = rm + ro - fabs(d);
-        if (overlap < 0.0) { touching = 0; break; }
-        if (overlap < best) { best = overlap; nx = d < 0.0 ? -ex : ex; ny = d < 0.0 ? -ey : ey; }
-    }
-    if (touching) {
-        /* contact points: object vertices inside the mover, mover vertices inside the object; depth along n. If the boxes
+    /* 2. contact geometry per pair */
+    push_pair pr[2];
+    const double co = cos(o->th), so = sin(o->th);
+    const double reach = sqrt(ax * ax + ay * ay) + h * sqrt(2.0), reach2 = reach * reach;
+    const double sx[4] = {-1, -1, 1, 1}, sy[4] = {-1, 1, 1, -1};
+    for (int i = 0; i < nm; ++i) {
+        const body2 *m = mv + i;
+        push_pair *q = pr + i;
+        q->np = 0; q->nx = 0.0; q->ny = 0.0;
+        const double dx = o->x - m->x, dy = o->y - m->y;
+        if (dx * dx + dy * dy > reach2) continue; /* broad phase: the circumscribed circles are apart */
+        const double cm = cos(m->th), sm = sin(m->th);
+        const double axes[4][2] = {{cm, sm}, {-sm, cm}, {co, so}, {-so, co}};
+        double best = INFINITY, nx = 0.0, ny = 0.0;
+        int touching = 1;
+        for (int k = 0; k < 4; ++k) {
+            const double ex = axes[k][0], ey = axes[k][1];
+            const double rm = ax * fabs(ex * cm + ey * sm) + ay * fabs(-ex * sm + ey * cm);
+            const double ro = h * fabs(ex * co + ey * so) + h * fabs(-ex * so + ey * co);
+            const double d = dx * ex + dy * ey;
+            const double overlap = rm + ro - fabs(d);
+            if (overlap < 0.0) { touching = 0; break; }
+            if (overlap < best) { best = overlap; nx = d < 0.0 ? -ex : ex; ny = d < 0.0 ? -ey : ey; }
+        }
+        if (!touching) continue;
+        /* contact points: object vertices inside the mover, then mover vertices inside the object; depth along n. If the boxes
          * cross without a vertex inside (rare), one point midway between the centres with the SAT depth. */
-        double cx[9], cy[9], dep[9], jn[9], jt[9];
+        double cx[GPRO_PUSH_SLOTS], cy[GPRO_PUSH_SLOTS], dep[GPRO_PUSH_SLOTS];
         int np = 0;
-        const double sx[4] = {-1, -1, 1, 1}, sy[4] = {-1, 1, 1, -1};
         const double rm_n = ax * fabs(nx * cm + ny * sm) + ay * fabs(-nx * sm + ny * cm);
         const double ro_n = h * fabs(nx * co + ny * so) + h * fabs(-nx * so + ny * co);
         for (int k = 0; k < 4; ++k) { /* object vertex in the mover frame */
             const double vx = o->x + co * (sx[k] * h) - so * (sy[k] * h), vy = o->y + so * (sx[k] * h) + co * (sy[k] * h);
             const double lx = (vx - m->x) * cm + (vy - m->y) * sm, ly = -(vx - m->x) * sm + (vy - m->y) * cm;
-            if (fabs(lx) <= ax && fabs(ly) <= ay) {
-                cx[np] = vx; cy[np] = vy; dep[np] = rm_n - ((vx - m->x) * nx + (vy - m->y) * ny); jn[np] = 0.0; jt[np] = 0.0; ++np;
+            if (fabs(lx) <= ax && fabs(ly) <= ay && np < GPRO_PUSH_SLOTS) {
+                cx[np] = vx; cy[np] = vy; dep[np] = rm_n - ((vx - m->x) * nx + (vy - m->y) * ny); ++np;
             }
         }
         for (int k = 0; k < 4; ++k) { /* mover vertex in the object frame */
             const double vx = m->x + cm * (sx[k] * ax) - sm * (sy[k] * ay), vy = m->y + sm * (sx[k] * ax) + cm * (sy[k] * ay);
             const double lx = (vx - o->x) * co + (vy - o->y) * so, ly = -(vx - o->x) * so + (vy - o->y) * co;
-            if (fabs(lx) <= h && fabs(ly) <= h) {
-                cx[np] = vx; cy[np] = vy; dep[np] = ro_n + ((vx - o->x) * nx + (vy - o->y) * ny); jn[np] = 0.0; jt[np] = 0.0; ++np;
+            if (fabs(lx) <= h && fabs(ly) <= h && np < GPRO_PUSH_SLOTS) {
+                cx[np] = vx; cy[np] = vy; dep[np] = ro_n + ((vx - o->x) * nx + (vy - o->y) * ny); ++np;
             }
         }
-        if (np == 0) { cx[0] = m->x + 0.5 * dx; cy[0] = m->y + 0.5 * dy; dep[0] = best; jn[0] = 0.0; jt[0] = 0.0; np = 1; }
-        const double tx = -ny, ty = nx, mu = pp->friction_contact;
-        for (int it = 0; it < 4; ++it) { /* sequential impulses */
-            for (int k = 0; k < np; ++k) {
-                const double rmx = cx[k] - m->x, rmy = cy[k] - m->y, rox = cx[k] - o->x, roy = cy[k] - o->y;
+        if (np == 0) { cx[0] = m->x + 0.5 * dx; cy[0] = m->y + 0.5 * dy; dep[0] = best; np = 1; }
+        q->np = np; q->nx = nx; q->ny = ny;
+        const double tx = -ny, ty = nx;
+        for (int k = 0; k < np; ++k) {
+            q->rmx[k] = cx[k] - m->x; q->rmy[k] = cy[k] - m->y; q->rox[k] = cx[k] - o->x; q->roy[k] = cy[k] - o->y;
+            q->rmn[k] = cross2(q->rmx[k], q->rmy[k], nx, ny); q->ron[k] = cross2(q->rox[k], q->roy[k], nx, ny);
+            q->rmt[k] = cross2(q->rmx[k], q->rmy[k], tx, ty); q->rot_[k] = cross2(q->rox[k], q->roy[k], tx, ty);
+            q->inv_kn[k] = 1.0 / (inv_mm + inv_mo + q->rmn[k] * q->rmn[k] * inv_Im + q->ron[k] * q->ron[k] * inv_Io);
+            q->inv_kt[k] = 1.0 / (inv_mm + inv_mo + q->rmt[k] * q->rmt[k] * inv_Im + q->rot_[k] * q->rot_[k] * inv_Io);
+            q->bias[k] = (dep[k] > 0.0 ? dep[k] : 0.0) / pp->contact_timeconst; /* penetration recovery velocity */
+            q->jn[k] = 0.0; q->jt[k] = 0.0;
+        }
+    }
+    /* 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points */
+    const double mu = pp->friction_contact;
+    for (int it = 0; it < 4; ++it) {
+        for (int i = 0; i < nm; ++i) {
+            body2 *m = mv + i;
+            push_pair *q = pr + i;
+            const double nx = q->nx, ny = q->ny, tx = -ny, ty = nx;
+            for (int k = 0; k < q->np; ++k) {
+                const double rmx = q->rmx[k], rmy = q->rmy[k], rox = q->rox[k], roy = q->roy[k];
                 double rvx = (o->vx - o->w * roy) - (m->vx - m->w * rmy), rvy = (o->vy + o->w * rox) - (m->vy + m->w * rmx);
-                const double rmn = cross2(rmx, rmy, nx, ny), ron = cross2(rox, roy, nx, ny);
-                const double kn = inv_mm + inv_mo + rmn * rmn * inv_Im + ron * ron * inv_Io;
-                const double bias = (dep[k] > 0.0 ? dep[k] : 0.0) / pp->contact_timeconst; /* penetration recovery velocity */
-                double dj = -((rvx * nx + rvy * ny) - bias) / kn;
-                double jn_new = jn[k] + dj; if (jn_new < 0.0) jn_new = 0.0;
-                dj = jn_new - jn[k]; jn[k] = jn_new;
-                m->vx -= dj * nx * inv_mm; m->vy -= dj * ny * inv_mm; m->w -= dj * rmn * inv_Im;
-                o->vx += dj * nx * inv_mo; o->vy += dj * ny * inv_mo; o->w += dj * ron * inv_Io;
+                double dj = -((rvx * nx + rvy * ny) - q->bias[k]) * q->inv_kn[k];
+                double jn_new = q->jn[k] + dj; if (jn_new < 0.0) jn_new = 0.0;
+                dj = jn_new - q->jn[k]; q->jn[k] = jn_new;
+                m->vx -= dj * nx * inv_mm; m->vy -= dj * ny * inv_mm; m->w -= dj * q->rmn[k] * inv_Im;
+                o->vx += dj * nx * inv_mo; o->vy += dj * ny * inv_mo; o->w += dj * q->ron[k] * inv_Io;
                 /* Coulomb friction at the point */
                 rvx = (o->vx - o->w * roy) - (m->vx - m->w * rmy); rvy = (o->vy + o->w * rox) - (m->vy + m->w * rmx);
-                const double rmt = cross2(rmx, rmy, tx, ty), rot_ = cross2(rox, roy, tx, ty);
-                const double kt = inv_mm + inv_mo + rmt * rmt * inv_Im + rot_ * rot_ * inv_Io;
-                double djt = -(rvx * tx + rvy * ty) / kt;
-                double lim = mu * jn[k], jt_new = jt[k] + djt;
+                double djt = -(rvx * tx + rvy * ty) * q->inv_kt[k];
+                double lim = mu * q->jn[k], jt_new = q->jt[k] + djt;
                 if (jt_new > lim) jt_new = lim;
                 if (jt_new < -lim) jt_new = -lim;
-                djt = jt_new - jt[k]; jt[k] = jt_new;
-                m->vx -= djt * tx * inv_mm; m->vy -= djt * ty * inv_mm; m->w -= djt * rmt * inv_Im;
-                o->vx += djt * tx * inv_mo; o->vy += djt * ty * inv_mo; o->w += djt * rot_ * inv_Io;
+                djt = jt_new - q->jt[k]; q->jt[k] = jt_new;
+                m->vx -= djt * tx * inv_mm; m->vy -= djt * ty * inv_mm; m->w -= djt * q->rmt[k] * inv_Im;
+                o->vx += djt * tx * inv_mo; o->vy += djt * ty * inv_mo; o->w += djt * q->rot_[k] * inv_Io;
             }
         }
     }
-    /* 3. positions with the new velocities */
-    m->x += dt * m->vx; m->y += dt * m->vy; m->th += dt * m->w;
+    /* 4. positions with the new velocities */
+    for (int i = 0; i < nm; ++i) { body2 *m = mv + i; m->x += dt * m->vx; m->y += dt * m->vy; m->th += dt * m->w; }
     o->x += dt * o->vx; o->y += dt * o->vy; o->th += dt * o->w;
 }
 
-/* _get_obs (PU:529-576), _get_info (PU:578-607), compute_reward / compute_terminated (PU:457-527) */
-static void push_observe(const env_ctx *c, const gpro_push_params *pp, uint32_t key, uint32_t q0, const double *pos, const double *vel,
-                         const double *acc, const double *object, const double *goal, int wc, int64_t e, gpro_step_out *out, double *margin) {
+/* _get_obs (PU:529-576), _get_info (PU:578-607), compute_reward / compute_terminated (PU:457-527); nm movers: the observation
+ * keeps the reference's np.concatenate((pos, vel[, acc]), axis=0).flatten() = all positions, all velocities[, all accelerations];
+ * a mover-mover collision (2 movers) counts like a wall collision */
+static void push_observe(const env_ctx *c, const gpro_push_params *pp, const uint32_t *keys, uint32_t q0, const double *pos, const double *vel,
+                         const double *acc, const double *object, const double *goal, int wc, int mc, int64_t e, gpro_step_out *out,
+                         double *margin) {
     const gpro_env_cfg *cfg = c->cfg;
-    const int od = cfg->learn_jerk ? 6 : 4;
-    double n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0;
-    if (c->noise) { gpro_rng_normal_pair(key, q0, &n0, &n1); gpro_rng_normal_pair(key, q0 + 1u, &n2, &n3); }
-    if (pp->object_noise != 0.0) gpro_rng_normal_pair(key, q0 + 2u, &n4, &n5);
+    const int nm = cfg->num_movers;
+    const int od = (cfg->learn_jerk ? 6 : 4) * nm;
     double *o = out->observation + od * e;
-    o[0] = q32(cfg, pos[0] + cfg->std_noise[0] * n0); o[1] = q32(cfg, pos[1] + cfg->std_noise[0] * n1); /* PU:551 */
-    o[2] = q32(cfg, vel[0] + cfg->std_noise[1] * n2); o[3] = q32(cfg, vel[1] + cfg->std_noise[1] * n3); /* PU:552 */
-    if (cfg->learn_jerk) { o[4] = q32(cfg, acc[0]); o[5] = q32(cfg, acc[1]); }                          /* PU:553-555 */
+    for (int i = 0; i < nm; ++i) {
+        double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        if (c->noise) { gpro_rng_normal_pair(keys[i], q0, &n0, &n1); gpro_rng_normal_pair(keys[i], q0 + 1u, &n2, &n3); }
+        o[2 * i] = q32(cfg, pos[2 * i] + cfg->std_noise[0] * n0); o[2 * i + 1] = q32(cfg, pos[2 * i + 1] + cfg->std_noise[0] * n1); /* PU:551 */
+        o[2 * nm + 2 * i] = q32(cfg, vel[2 * i] + cfg->std_noise[1] * n2); o[2 * nm + 2 * i + 1] = q32(cfg, vel[2 * i + 1] + cfg->std_noise[1] * n3); /* PU:552 */
+        if (cfg->learn_jerk) { o[4 * nm + 2 * i] = q32(cfg, acc[2 * i]); o[4 * nm + 2 * i + 1] = q32(cfg, acc[2 * i + 1]); }      /* PU:553-555 */
+    }
+    double n4 = 0, n5 = 0;
+    if (pp->object_noise != 0.0) gpro_rng_normal_pair(keys[0], q0 + 2u, &n4, &n5);
     double *ag = out->achieved_goal + 2 * e, *dg = out->desired_goal + 2 * e;
     ag[0] = q32(cfg, object[0] + pp->object_noise * n4); ag[1] = q32(cfg, object[1] + pp->object_noise * n5); /* PU:564-565 */
     dg[0] = q32(cfg, goal[0]); dg[1] = q32(cfg, goal[1]);
     double dx = ag[0] - dg[0], dy = ag[1] - dg[1], dist = sqrt(dx * dx + dy * dy);
     track(margin, dist, cfg->threshold_pos);
     int reached = dist <= cfg->threshold_pos;
-    double r = -50.0 * (double)(wc != 0);       /* PU:521, reward_wall_collision = -50 (PU:219) */
-    r += -1.0 * (double)(!wc);                  /* PU:522 */
-    if (reached && !wc) r = 0.0;                /* PU:523 */
+    const int coll = wc || mc;
+    double r = -50.0 * (double)(coll != 0);     /* PU:521, reward_wall_collision = -50 (PU:219) */
+    r += -1.0 * (double)(!coll);                /* PU:522 */
+    if (reached && !coll) r = 0.0;              /* PU:523 */
     out->reward[e] = r;
     out->terminated[e] = (r == -50.0);          /* PU:475 */
-    out->is_success[e] = reached && !wc;        /* PU:602 */
-    out->mover_collision[e] = 0;
+    out->is_success[e] = reached && !coll;      /* PU:602 */
+    out->mover_collision[e] = (uint8_t)mc;
     out->wall_collision[e] = (uint8_t)wc;
 }
 
+/* PU:373-417. opt_start / opt_goal: the reset options 'mover_start_xy_pos' [2 nm] / 'object_goal_xy_pos' [2] of this env (NULL:
+ * sampled). 2 movers: their starts are re-drawn together until the two collision circles (with the safety offset) are apart. */
 static void push_reset_one(const env_ctx *c, const gpro_push_params *pp, uint64_t seed, uint64_t tick, int64_t env_id, int64_t e, double *pos,
-                           double *vel, double *acc, double *rot, double *object, double *goal, int32_t *elapsed, gpro_step_out *out,
-                           double *margin) {
+                           double *vel, double *acc, double *rot, double *object, double *goal, int32_t *elapsed, const double *opt_start,
+                           const double *opt_goal, gpro_step_out *out, double *margin) {
     const gpro_env_cfg *cfg = c->cfg;
-    const uint32_t ks = gpro_rng_key(seed, tick, KIND_RESET_START, (uint64_t)env_id, 0u);
+    const int nm = cfg->num_movers;
+    uint32_t ks[2], kr[2], kn[2];
+    for (int i = 0; i < nm; ++i) {
+        ks[i] = gpro_rng_key(seed, tick, KIND_RESET_START, (uint64_t)env_id, (uint32_t)i);
+        kr[i] = gpro_rng_key(seed, tick, KIND_RESET_START, (uint64_t)env_id, (uint32_t)(GPRO_MAX_MOVERS + i));
+        kn[i] = gpro_rng_key(seed, tick, KIND_RESET_NOISE, (uint64_t)env_id, (uint32_t)i);
+    }
     const uint32_t kg = gpro_rng_key(seed, tick, KIND_RESET_GOAL, (uint64_t)env_id, 0u);
-    const uint32_t kn = gpro_rng_key(seed, tick, KIND_RESET_NOISE, (uint64_t)env_id, 0u);
-    for (int d = 0; d < 2; ++d) /* PU:389-391 */
-        pos[d] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * gpro_rng_uniform(ks, (uint32_t)d));
+    if (opt_start) {
+        for (int k = 0; k < 2 * nm; ++k) pos[k] = q32(cfg, opt_start[k]); /* PU:389-391 */
+    } else {
+        for (int trial = 0; trial < cfg->max_reset_trials; ++trial) {
+            for (int i = 0; i < nm; ++i)
+                for (int d = 0; d < 2; ++d) { /* PU:389-391; re-draws (2 movers only) come from a stream of their own */
+                    const double u = trial == 0 ? gpro_rng_uniform(ks[i], (uint32_t)d) : gpro_rng_uniform(kr[i], 2u * (uint32_t)(trial - 1) + (uint32_t)d);
+                    pos[2 * i + d] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u);
+                }
+            if (nm == 1) break;
+            double qp[2 * 7];
+            noisy_qpos(c, ks, 0, nm, pos, 0.0, 0, qp);
+            if (!pair_any(c, qp, 1, margin)) break;
+        }
+    }
     for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PU:396-407 */
         for (int d = 0; d < 2; ++d)
-            object[d] = q32(cfg, pp->obj_min_xy[d] + (pp->obj_max_xy[d] - pp->obj_min_xy[d]) * gpro_rng_uniform(ks, 2u + 2u * (uint32_t)trial + (uint32_t)d));
-        double dx = object[0] - pos[0], dy = object[1] - pos[1], dist = sqrt(dx * dx + dy * dy);
-        track(margin, dist, pp->min_mo_dist);
-        if (dist > pp->min_mo_dist) break; /* PU:407, strict */
+            object[d] = q32(cfg, pp->obj_min_xy[d] + (pp->obj_max_xy[d] - pp->obj_min_xy[d]) * gpro_rng_uniform(ks[0], 2u + 2u * (uint32_t)trial + (uint32_t)d));
+        int ok = 1;
+        for (int i = 0; i < nm; ++i) {
+            double dx = object[0] - pos[2 * i], dy = object[1] - pos[2 * i + 1], dist = sqrt(dx * dx + dy * dy);
+            track(margin, dist, pp->min_mo_dist);
+            if (!(dist > pp->min_mo_dist)) ok = 0; /* PU:407, strict, every mover */
+        }
+        if (ok) break;
     }
     for (int d = 0; d < 2; ++d) /* PU:412-414 */
-        goal[d] = q32(cfg, pp->obj_min_xy[d] + (pp->obj_max_xy[d] - pp->obj_min_xy[d]) * gpro_rng_uniform(kg, (uint32_t)d));
-    vel[0] = vel[1] = acc[0] = acc[1] = 0.0; rot[0] = rot[1] = 0.0;
+        goal[d] = opt_goal ? q32(cfg, opt_goal[d]) : q32(cfg, pp->obj_min_xy[d] + (pp->obj_max_xy[d] - pp->obj_min_xy[d]) * gpro_rng_uniform(kg, (uint32_t)d));
+    for (int k = 0; k < 2 * nm; ++k) { vel[k] = 0.0; acc[k] = 0.0; rot[k] = 0.0; }
     object[2] = object[3] = object[4] = object[5] = 0.0;
     *elapsed = 0;
-    double qp[7];
-    noisy_qpos(c, &kn, 0, 1, pos, cfg->std_noise[0], 1, qp);
+    double qp[2 * 7];
+    noisy_qpos(c, kn, 0, nm, pos, cfg->std_noise[0], 1, qp);
     int wc = wall_any(c, qp, 1, margin); /* BE:1799-1801 */
-    push_observe(c, pp, kn, 2u, pos, vel, acc, object, goal, wc, e, out, margin);
+    int mc = 0;
+    if (nm > 1) { noisy_qpos(c, kn, 1, nm, pos, cfg->std_noise[0], 1, qp); mc = pair_any(c, qp, 0, margin); } /* BE:1803-1805 */
+    push_observe(c, pp, kn, 2u, pos, vel, acc, object, goal, wc, mc, e, out, margin);
     out->truncated[e] = 0;
 }
 
 int32_t gpro_pushing_reset(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
-                           int64_t env_id_offset, const uint8_t *mask, double *pos, double *vel, double *acc, double *mover_rot,
-                           double *object, double *goal, int32_t *elapsed, gpro_step_out *out) {
-    if (cfg->num_movers != 1) return -1;
+                           int64_t env_id_offset, const uint8_t *mask, const double *opt_mover_start, const double *opt_goal, double *pos,
+                           double *vel, double *acc, double *mover_rot, double *object, double *goal, int32_t *elapsed, gpro_step_out *out) {
+    const int nm = cfg->num_movers;
+    if (nm < 1 || nm > 2) return -1;
     env_ctx c;
     ctx_init(&c, cfg);
     for (int64_t e = 0; e < num_envs; ++e) {
         if (mask && !mask[e]) continue;
         double m = INFINITY;
-        push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos + 2 * e, vel + 2 * e, acc + 2 * e, mover_rot + 2 * e, object + 6 * e,
-                       goal + 2 * e, elapsed + e, out, out->margin ? &m : NULL);
+        push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos + 2 * nm * e, vel + 2 * nm * e, acc + 2 * nm * e, mover_rot + 2 * nm * e,
+                       object + 6 * e, goal + 2 * e, elapsed + e, opt_mover_start ? opt_mover_start + 2 * nm * e : NULL,
+                       opt_goal ? opt_goal + 2 * e : NULL, out, out->margin ? &m : NULL);
         out->reward[e] = 0.0; out->terminated[e] = 0;
         if (out->margin) out->margin[e] = m;
     }
@@ -973,52 +1046,66 @@ int32_t gpro_pushing_reset(const gpro_env_cfg *cfg, const gpro_push_params *pp, 
 int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
                           int64_t env_id_offset, const double *action, double *pos_a, double *vel_a, double *acc_a, double *rot_a,
                           double *obj_a, double *goal_a, int32_t *elapsed_a, int32_t autoreset, gpro_step_out *out) {
-    if (cfg->num_movers != 1) return -1;
+    const int nm = cfg->num_movers;
+    if (nm < 1 || nm > 2) return -1;
     env_ctx c;
     ctx_init(&c, cfg);
     const double dt = cfg->dt;
-    const int od = cfg->learn_jerk ? 6 : 4;
+    const int od = (cfg->learn_jerk ? 6 : 4) * nm;
     for (int64_t e = 0; e < num_envs; ++e) {
-        double *pos = pos_a + 2 * e, *vel = vel_a + 2 * e, *acc = acc_a + 2 * e, *rot = rot_a + 2 * e, *obj = obj_a + 6 * e, *goal = goal_a + 2 * e;
+        double *pos = pos_a + 2 * nm * e, *vel = vel_a + 2 * nm * e, *acc = acc_a + 2 * nm * e, *rot = rot_a + 2 * nm * e, *obj = obj_a + 6 * e,
+               *goal = goal_a + 2 * e;
         double mg = INFINITY;
         double *margin = out->margin ? &mg : NULL;
         if (autoreset == 2 && elapsed_a[e] < 0) {
-            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, out, margin);
+            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, NULL, NULL, out, margin);
             out->reward[e] = 0.0; out->terminated[e] = 0;
             if (out->margin) out->margin[e] = mg;
             continue;
         }
-        const uint32_t key = gpro_rng_key(seed, tick, KIND_STEP_NOISE, (uint64_t)(env_id_offset + e), 0u);
+        uint32_t keys[2];
+        for (int i = 0; i < nm; ++i) keys[i] = gpro_rng_key(seed, tick, KIND_STEP_NOISE, (uint64_t)(env_id_offset + e), (uint32_t)i);
         const double lim = cfg->learn_jerk ? cfg->j_max : cfg->a_max;
-        double a[2] = {fmin(fmax(action[2 * e], -lim), lim), fmin(fmax(action[2 * e + 1], -lim), lim)};
-        body2 m = {pos[0], pos[1], rot[0], vel[0], vel[1], rot[1]}, o = {obj[0], obj[1], obj[2], obj[3], obj[4], obj[5]};
-        int wc = 0;
+        double a[4];
+        for (int k = 0; k < 2 * nm; ++k) a[k] = fmin(fmax(action[2 * nm * e + k], -lim), lim);
+        body2 m[2], o = {obj[0], obj[1], obj[2], obj[3], obj[4], obj[5]};
+        for (int i = 0; i < nm; ++i) { body2 b = {pos[2 * i], pos[2 * i + 1], rot[2 * i], vel[2 * i], vel[2 * i + 1], rot[2 * i + 1]}; m[i] = b; }
+        int wc = 0, mc = 0;
         for (int cyc = 0; cyc < cfg->num_cycles; ++cyc) {
-            /* _mujoco_step_callback (PU:419-455) */
-            double n0 = 0, n1 = 0;
-            if (c.noise) gpro_rng_normal_pair(key, 3u * (uint32_t)cyc, &n0, &n1);
-            double nv[2] = {m.vx + cfg->std_noise[1] * n0, m.vy + cfg->std_noise[1] * n1}, u[2], vals[2], ders[2];
-            if (cfg->learn_jerk) {
-                double acc_tmp[2], j1[2];
-                clamp_one(acc, cfg->a_max, a, dt, acc_tmp, j1, margin);
-                clamp_one(nv, cfg->v_max, acc_tmp, dt, vals, ders, margin);
-                if (acc_tmp[0] != ders[0] || acc_tmp[1] != ders[1]) { u[0] = (ders[0] - acc[0]) / dt; u[1] = (ders[1] - acc[1]) / dt; }
-                else { u[0] = j1[0]; u[1] = j1[1]; }
-                acc[0] = acc[0] + dt * u[0]; acc[1] = acc[1] + dt * u[1];
-            } else {
-                clamp_one(nv, cfg->v_max, a, dt, vals, ders, margin);
-                acc[0] = ders[0]; acc[1] = ders[1];
+            /* _mujoco_step_callback (PU:419-455), per mover */
+            double u[2][2];
+            for (int i = 0; i < nm; ++i) {
+                double n0 = 0, n1 = 0;
+                if (c.noise) gpro_rng_normal_pair(keys[i], 3u * (uint32_t)cyc, &n0, &n1);
+                double nv[2] = {m[i].vx + cfg->std_noise[1] * n0, m[i].vy + cfg->std_noise[1] * n1}, uu[2], vals[2], ders[2];
+                double *ac = acc + 2 * i;
+                if (cfg->learn_jerk) {
+                    double acc_tmp[2], j1[2];
+                    clamp_one(ac, cfg->a_max, a + 2 * i, dt, acc_tmp, j1, margin);
+                    clamp_one(nv, cfg->v_max, acc_tmp, dt, vals, ders, margin);
+                    if (acc_tmp[0] != ders[0] || acc_tmp[1] != ders[1]) { uu[0] = (ders[0] - ac[0]) / dt; uu[1] = (ders[1] - ac[1]) / dt; }
+                    else { uu[0] = j1[0]; uu[1] = j1[1]; }
+                    ac[0] = ac[0] + dt * uu[0]; ac[1] = ac[1] + dt * uu[1];
+                } else {
+                    clamp_one(nv, cfg->v_max, a + 2 * i, dt, vals, ders, margin);
+                    ac[0] = ders[0]; ac[1] = ders[1];
+                }
+                u[i][0] = ac[0]; u[i][1] = ac[1];
             }
-            push_cycle(cfg, pp, &m, &o, acc[0], acc[1]); /* mj_step (BE:1882): engine model gpr-push-v1 */
-            double xy[2] = {m.x, m.y}, qp[7];
-            noisy_qpos(&c, &key, 3u * (uint32_t)cyc + 1u, 1, xy, cfg->std_noise[0], 1, qp);
-            wc = wall_any(&c, qp, 0, margin); /* BE:1888-1894; the mover check is trivially False with one mover (PU:600) */
-            if (wc) break;
+            push_cycle(cfg, pp, nm, m, &o, (const double (*)[2])u); /* mj_step (BE:1882): engine model gpr-push-v2 */
+            double xy[4], qp[2 * 7];
+            for (int i = 0; i < nm; ++i) { xy[2 * i] = m[i].x; xy[2 * i + 1] = m[i].y; }
+            noisy_qpos(&c, keys, 3u * (uint32_t)cyc + 1u, nm, xy, cfg->std_noise[0], 1, qp);
+            wc = wall_any(&c, qp, 0, margin); /* BE:1888-1894 */
+            if (nm > 1) { noisy_qpos(&c, keys, 3u * (uint32_t)cyc + 2u, nm, xy, cfg->std_noise[0], 1, qp); mc = pair_any(&c, qp, 0, margin); } /* BE:1896-1901 */
+            if (wc || mc) break;
         }
-        pos[0] = q32(cfg, m.x); pos[1] = q32(cfg, m.y); vel[0] = q32(cfg, m.vx); vel[1] = q32(cfg, m.vy);
-        acc[0] = q32(cfg, acc[0]); acc[1] = q32(cfg, acc[1]); rot[0] = q32(cfg, m.th); rot[1] = q32(cfg, m.w);
+        for (int i = 0; i < nm; ++i) {
+            pos[2 * i] = q32(cfg, m[i].x); pos[2 * i + 1] = q32(cfg, m[i].y); vel[2 * i] = q32(cfg, m[i].vx); vel[2 * i + 1] = q32(cfg, m[i].vy);
+            acc[2 * i] = q32(cfg, acc[2 * i]); acc[2 * i + 1] = q32(cfg, acc[2 * i + 1]); rot[2 * i] = q32(cfg, m[i].th); rot[2 * i + 1] = q32(cfg, m[i].w);
+        }
         obj[0] = q32(cfg, o.x); obj[1] = q32(cfg, o.y); obj[2] = q32(cfg, o.th); obj[3] = q32(cfg, o.vx); obj[4] = q32(cfg, o.vy); obj[5] = q32(cfg, o.w);
-        push_observe(&c, pp, key, 3u * (uint32_t)cfg->num_cycles, pos, vel, acc, obj, goal, wc, e, out, margin);
+        push_observe(&c, pp, keys, 3u * (uint32_t)cfg->num_cycles, pos, vel, acc, obj, goal, wc, mc, e, out, margin);
         elapsed_a[e] += 1;
         int trunc = cfg->max_episode_steps > 0 && elapsed_a[e] >= cfg->max_episode_steps;
         out->truncated[e] = (uint8_t)trunc;
@@ -1028,9 +1115,10 @@ int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, i
             if (out->final_achieved_goal) memcpy(out->final_achieved_goal + 2 * e, out->achieved_goal + 2 * e, sizeof(double) * 2);
             if (out->final_desired_goal) memcpy(out->final_desired_goal + 2 * e, out->desired_goal + 2 * e, sizeof(double) * 2);
             double r = out->reward[e];
-            uint8_t t = out->terminated[e], s = out->is_success[e], pw = out->wall_collision[e];
-            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, out, margin);
+            uint8_t t = out->terminated[e], s = out->is_success[e], pw = out->wall_collision[e], pm = out->mover_collision[e];
+            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, NULL, NULL, out, margin);
             out->reward[e] = r; out->terminated[e] = t; out->truncated[e] = (uint8_t)trunc; out->is_success[e] = s; out->wall_collision[e] = pw;
+            out->mover_collision[e] = pm;
         } else if (done && autoreset == 2) {
             elapsed_a[e] = -1;
         }

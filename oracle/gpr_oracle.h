@@ -130,13 +130,14 @@ int32_t gpro_planning_step_mt(const gpro_env_cfg *cfg, int64_t num_envs, uint64_
 
 
 /* ======================================================================================================================
- * BenchmarkPushingEnv (envs/manipulation/benchmark_pushing_env.py, "PU"): 1 mover + 1 pushed box on 3x3 tiles.
+ * BenchmarkPushingEnv (envs/manipulation/benchmark_pushing_env.py, "PU"): 1 mover (the reference, PU:196) or 2 movers
+ * (BASELINE.json's config 3; engine-defined) + 1 pushed box on 3x3 tiles.
  *
  * PINNED (reference tests / code): the mover's x,y actuation and clamping (PU:419-448 == PL:420-450; 24 closed-form tests),
  * observation / reward / terminated / info (PU:457-607), reset sampling predicates (PU:373-417), wall check.
  * UNPINNED -- "parity unpinned": everything that MuJoCo's contact solver does in the reference (mover-object and object-tile
  * contact, friction, the soft impedance hold of the mover's yaw). MuJoCo is not available to this pipeline and no reference
- * test exercises contact, so the contact physics below is the ENGINE'S OWN planar rigid-body model "gpr-push-v1"
+ * test exercises contact, so the contact physics below is the ENGINE'S OWN planar rigid-body model "gpr-push-v2"
  * (documented in DESIGN.md): 3-DoF bodies, OBB-OBB contact by SAT, sequential impulses with Coulomb friction and a
  * 20 ms penetration-recovery time constant (MuJoCo's default solref), Coulomb + torsional friction against the tiles,
  * the reference's joint damping (PU:335) and impedance gains (PU:261-267, IMP:42-47) applied to the yaw.
@@ -158,11 +159,13 @@ typedef struct {
     double obj_min_xy[2], obj_max_xy[2]; /* PU:257-258 */
 } gpro_push_params;
 
-/* state per env: mover pos/vel/acc [E][2]; mover_rot [E][2] = (yaw, yaw rate); object [E][6] = (x, y, yaw, vx, vy, yaw rate);
- * goal [E][2]; elapsed [E]. Outputs as gpro_step_out with observation [E][4] (or [E][6] in jerk mode), achieved/desired [E][2]. */
+/* state per env (nm = cfg->num_movers in {1, 2}): mover pos/vel/acc [E][2 nm]; mover_rot [E][2 nm] = (yaw, yaw rate) per mover; object
+ * [E][6] = (x, y, yaw, vx, vy, yaw rate); goal [E][2]; elapsed [E]. Outputs as gpro_step_out with observation [E][4 nm] = all
+ * positions, all velocities (or [E][6 nm] with all accelerations in jerk mode), achieved/desired [E][2]. opt_mover_start [E][2 nm] /
+ * opt_goal [E][2]: the reset options 'mover_start_xy_pos' / 'object_goal_xy_pos' (PU:389-391, 412-414), NULL = sampled. */
 int32_t gpro_pushing_reset(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
-                           int64_t env_id_offset, const uint8_t *mask, double *pos, double *vel, double *acc, double *mover_rot,
-                           double *object, double *goal, int32_t *elapsed, gpro_step_out *out);
+                           int64_t env_id_offset, const uint8_t *mask, const double *opt_mover_start, const double *opt_goal, double *pos,
+                           double *vel, double *acc, double *mover_rot, double *object, double *goal, int32_t *elapsed, gpro_step_out *out);
 int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
                           int64_t env_id_offset, const double *action, double *pos, double *vel, double *acc, double *mover_rot,
                           double *object, double *goal, int32_t *elapsed, int32_t autoreset, gpro_step_out *out);

@@ -266,18 +266,19 @@ class PushParams(C.Structure):
 
 class OraclePushingEnv:
     """Batched BenchmarkPushingEnv on the CPU oracle (mover control / obs / reward pinned by the reference; contact physics is the
-    engine's own planar model gpr-push-v1 -- parity unpinned, see oracle/gpr_oracle.h)."""
+    engine's own planar model gpr-push-v2 -- parity unpinned, see oracle/gpr_oracle.h). num_movers = 1 is the reference's env,
+    2 the engine-defined variant of BASELINE.json's config 3."""
 
     def __init__(self, num_envs, mover_mass=1.24, mover_half=(0.0775, 0.0775), std_noise=1e-5, num_cycles=40, collision_params=None,
                  v_max=2.0, a_max=10.0, j_max=100.0, learn_jerk=False, threshold_pos=0.05, max_episode_steps=50, autoreset='same_step',
-                 env_id_offset=0, max_reset_trials=10000, storage_f32=False, dt=0.001, object_noise=1e-5):
+                 env_id_offset=0, max_reset_trials=10000, storage_f32=False, dt=0.001, object_noise=1e-5, num_movers=1, push_overrides=None):
         cp = dict(collision_params or {})
-        assert cp.get('shape', 'circle') == 'circle'
-        base = OraclePlanningEnv(np.ones((3, 3)), 1, num_envs, std_noise=std_noise, num_cycles=num_cycles, collision_params=cp, v_max=v_max,
+        assert cp.get('shape', 'circle') == 'circle' and num_movers in (1, 2)
+        base = OraclePlanningEnv(np.ones((3, 3)), num_movers, num_envs, std_noise=std_noise, num_cycles=num_cycles, collision_params=cp, v_max=v_max,
                                  a_max=a_max, j_max=j_max, learn_jerk=learn_jerk, threshold_pos=threshold_pos,
                                  max_episode_steps=max_episode_steps, autoreset=autoreset, env_id_offset=env_id_offset,
                                  max_reset_trials=max_reset_trials, storage_f32=storage_f32, dt=dt)
-        self.base, self.cfg, self.E = base, base.cfg, int(num_envs)
+        self.base, self.cfg, self.E, self.NM = base, base.cfg, int(num_envs), int(num_movers)
         self.autoreset, self.env_id_offset = base.autoreset, env_id_offset
         c_size, off, off_w = cp.get('size', 0.11), cp.get('offset', 0.0), cp.get('offset_wall', 0.0)
         margin = c_size + off_w + off
@@ -287,9 +288,11 @@ class OraclePushingEnv:
         self.min_mo_dist = max(float(np.linalg.norm(obj_half + np.asarray(mover_half), ord=2)), c_size + off)  # PU:279-283
         self.pp = PushParams(mover_mass, (C.c_double * 2)(*mover_half), obj_half, 0.01, 0.01, 1.0, 1.0, 0.005, 9.81, 0.1, 0.02, object_noise,
                              self.min_mo_dist, (C.c_double * 2)(*self.obj_min), (C.c_double * 2)(*self.obj_max))
-        E = self.E
-        self.obs_dim = 6 if learn_jerk else 4
-        self.pos = np.zeros((E, 2)); self.vel = np.zeros((E, 2)); self.acc = np.zeros((E, 2)); self.rot = np.zeros((E, 2))
+        for k, v in (push_overrides or {}).items():  # (tests of the contact model's invariants switch friction / damping off)
+            setattr(self.pp, {'mover_half_size': 'mover_half', 'object_half_size': 'object_half'}.get(k, k), v)
+        E, NM = self.E, self.NM
+        self.obs_dim = (6 if learn_jerk else 4) * NM
+        self.pos = np.zeros((E, 2 * NM)); self.vel = np.zeros((E, 2 * NM)); self.acc = np.zeros((E, 2 * NM)); self.rot = np.zeros((E, 2 * NM))
         self.object = np.zeros((E, 6)); self.goal = np.zeros((E, 2)); self.elapsed = np.zeros(E, dtype=np.int32)
         self.seed, self.tick = 0, 0
         self.o = dict(observation=np.zeros((E, self.obs_dim)), achieved_goal=np.zeros((E, 2)), desired_goal=np.zeros((E, 2)), reward=np.zeros(E),
@@ -302,19 +305,21 @@ class OraclePushingEnv:
     def _result(self):
         return {k: (v.astype(bool) if v.dtype == np.uint8 else v.copy()) for k, v in self.o.items()}
 
-    def reset(self, seed=None, mask=None):
+    def reset(self, seed=None, mask=None, mover_start_xy_pos=None, object_goal_xy_pos=None):
         if seed is not None:
             self.seed, self.tick = int(seed), 0
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        ms = None if mover_start_xy_pos is None else np.ascontiguousarray(np.broadcast_to(np.asarray(mover_start_xy_pos, dtype=np.float64).reshape(-1, 2 * self.NM), (self.E, 2 * self.NM)))
+        og = None if object_goal_xy_pos is None else np.ascontiguousarray(np.broadcast_to(np.asarray(object_goal_xy_pos, dtype=np.float64).reshape(-1, 2), (self.E, 2)))
         rc = lib().gpro_pushing_reset(C.byref(self.cfg), C.byref(self.pp), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick),
-                                      C.c_int64(self.env_id_offset), _p(m), _p(self.pos), _p(self.vel), _p(self.acc), _p(self.rot),
+                                      C.c_int64(self.env_id_offset), _p(m), _p(ms), _p(og), _p(self.pos), _p(self.vel), _p(self.acc), _p(self.rot),
                                       _p(self.object), _p(self.goal), _p(self.elapsed), C.byref(self.out))
         assert rc == 0
         self.tick += 1
         return self._result()
 
     def step(self, action):
-        a = _f64(action).reshape(self.E, 2)
+        a = _f64(action).reshape(self.E, 2 * self.NM)
         rc = lib().gpro_pushing_step(C.byref(self.cfg), C.byref(self.pp), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick),
                                      C.c_int64(self.env_id_offset), _p(a), _p(self.pos), _p(self.vel), _p(self.acc), _p(self.rot),
                                      _p(self.object), _p(self.goal), _p(self.elapsed), C.c_int32(self.autoreset), C.byref(self.out))

@@ -39,3 +39,23 @@ def oracle():
     from oracle import oracle as _o
     _o.build()
     return _o
+
+
+METRICS_PATH = os.environ.get('GPR_PARITY_METRICS') or os.path.join(ROOT, 'gpurun_out', 'parity_metrics.json')
+
+
+def record_metric(test, **values):
+    """Parity tests persist what they MEASURED (largest error, fraction of flag mismatches ...) next to the bound they assert,
+    so that a later round can see a regression that still passes. On the GPU box the file lands in gpurun_out/ (merged back by
+    gpurun); the copy the round is judged on is profiles/round*_parity_metrics.json."""
+    try:
+        os.makedirs(os.path.dirname(METRICS_PATH), exist_ok=True)
+        data = {}
+        if os.path.exists(METRICS_PATH):
+            with open(METRICS_PATH) as f:
+                data = json.load(f)
+        data[test] = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in values.items()}
+        with open(METRICS_PATH, 'w') as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

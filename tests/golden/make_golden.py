@@ -19,6 +19,11 @@ known-answer cases the reference's own tests hold):
   reward_cases.npz               compute_reward / compute_terminated on batches incl. dist == threshold
   constants.json                 ctor-time tables (tile centres, 3x3 / 2x2 index lists, min/max xy, min_goal_dist)
   reset_predicates.npz           start / goal candidate sets with the accept decisions of _reset_callback's checks
+  obs_ordering.npz               BenchmarkPlanningEnv._get_obs (PL:536-573) called on the imported class with its three state getters
+                                 replaced by given arrays: the observation / achieved_goal / desired_goal orderings, acc and jerk mode
+  step_callback.npz              BenchmarkPlanningEnv._mujoco_step_callback (PL:420-450) called as written, per cycle: given
+                                 velocities / accelerations / actions -> the ctrl values it hands to MuJoCo (acc and jerk mode,
+                                 incl. the "velocity clamp overrides the jerk" branch PL:437-440)
 
 MuJoCo itself is not installed, so nothing here depends on mj_step (see _import_reference.py).
 """
@@ -517,7 +522,79 @@ def gen_reset_predicates(seed=21):
     print('reset_predicates done')
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 9. _get_obs orderings and the per-cycle control decision, from the imported class methods themselves
+# ----------------------------------------------------------------------------------------------------------
+def gen_obs_ordering(seed=31):
+    rng = np.random.default_rng(seed)
+    out = {}
+    for jerk in (False, True):
+        for M in (1, 3, 4):
+            env = planning_env(num_movers=M, learn_jerk=jerk, layout_tiles=np.ones((6, 6)))
+            pos = rng.uniform(0.2, 1.2, size=(M, 7)); vel = rng.uniform(-2, 2, size=(M, 6)); acc = rng.uniform(-10, 10, size=(M, 6))
+            goals = rng.uniform(0.2, 1.2, size=(M, 2))
+            env.get_mover_qpos_arr = lambda mover_names, add_noise=False, _a=pos: _a.copy()
+            env.get_mover_qvel_arr = lambda mover_names, add_noise=False, _a=vel: _a.copy()
+            env.get_mover_qacc_arr = lambda mover_names, add_noise=False, _a=acc: _a.copy()
+            env.goals = goals.copy()
+            o = BenchmarkPlanningEnv._get_obs(env)
+            tag = f'{"jerk" if jerk else "acc"}_M{M}'
+            out[tag + '_pos'] = pos[:, :2]; out[tag + '_vel'] = vel[:, :2]; out[tag + '_acc'] = acc[:, :2]; out[tag + '_goals'] = goals
+            for k in ('observation', 'achieved_goal', 'desired_goal'):
+                out[tag + '_' + k] = np.asarray(o[k])
+    np.savez_compressed(os.path.join(HERE, 'obs_ordering.npz'), **out)
+    print('obs_ordering.npz:', len(out), 'arrays')
+
+
+def gen_step_callback(seed=41, n=400):
+    import gymnasium_planar_robotics.envs.planning.benchmark_planning_env as PLMOD
+    rng = np.random.default_rng(seed)
+    out = {}
+    for jerk in (False, True):
+        M = 2
+        env = planning_env(num_movers=M, learn_jerk=jerk, layout_tiles=np.ones((6, 6)), v_max=2.0, a_max=10.0, j_max=100.0)
+        lim = 100.0 if jerk else 10.0
+        # speeds / accelerations from "far inside" to "at / beyond the limit" so that every branch of PL:432-443 is taken
+        def polar(mags):
+            ang = rng.uniform(0, 2 * np.pi, size=(n, M))
+            r = rng.choice(mags, size=(n, M)) * rng.uniform(0.97, 1.03, size=(n, M))
+            return np.stack([r * np.cos(ang), r * np.sin(ang)], axis=-1)
+
+        vel = polar([0.3, 1.2, 1.95, 2.0, 2.0, 2.05])
+        acc = polar([1.0, 6.0, 9.8, 10.0, 10.2])
+        act = rng.uniform(-lim, lim, size=(n, M * 2))
+        ctrl = np.zeros((n, M, 2))
+        captured = {}
+
+        def fake_set(model, data, actuator_name, value, _c=captured):
+            _c[actuator_name] = float(value)
+
+        orig = PLMOD.mujoco_utils.set_actuator_ctrl
+        PLMOD.mujoco_utils.set_actuator_ctrl = fake_set
+        try:
+            for i in range(n):
+                env.get_mover_qvel = lambda mover_name, add_noise=False, _i=i: np.concatenate([vel[_i, env.mover_names.index(mover_name)], np.zeros(4)])
+                env.get_mover_qacc = lambda mover_name, add_noise=False, _i=i: np.concatenate([acc[_i, env.mover_names.index(mover_name)], np.zeros(4)])
+                captured.clear()
+                BenchmarkPlanningEnv._mujoco_step_callback(env, act[i].copy())
+                for m in range(M):
+                    ctrl[i, m, 0] = captured[env.mover_actuator_x_names[m]]
+                    ctrl[i, m, 1] = captured[env.mover_actuator_y_names[m]]
+        finally:
+            PLMOD.mujoco_utils.set_actuator_ctrl = orig
+        tag = 'jerk' if jerk else 'acc'
+        out[tag + '_vel'] = vel; out[tag + '_acc'] = acc; out[tag + '_action'] = act; out[tag + '_ctrl'] = ctrl
+        changed = np.abs(ctrl.reshape(n, -1) - act).max(axis=1) > 1e-12
+        print(f'step_callback {tag}: {int(changed.sum())} of {n} cases leave the action changed')
+    out['dt'] = np.array(0.001); out['v_max'] = np.array(2.0); out['a_max'] = np.array(10.0); out['j_max'] = np.array(100.0)
+    np.savez_compressed(os.path.join(HERE, 'step_callback.npz'), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'round2':  # only the fixtures added in round 2 (the others are unchanged)
+        gen_obs_ordering()
+        gen_step_callback()
+        sys.exit(0)
     gen_qpos_ref_tests()
     gen_qpos_fuzz()
     gen_geometry()
@@ -527,3 +604,5 @@ if __name__ == '__main__':
     gen_reward()
     gen_constants()
     gen_reset_predicates()
+    gen_obs_ordering()
+    gen_step_callback()

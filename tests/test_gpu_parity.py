@@ -13,7 +13,7 @@ Tolerances
 import numpy as np
 import pytest
 
-from conftest import load_json, load_npz
+from conftest import load_json, load_npz, record_metric
 
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
@@ -305,6 +305,8 @@ def test_step_reset_vs_oracle(gpr, oracle, cfg_i, precision):
     assert frac_mismatch <= {'f64': 0.0, 'f32_f64acc': 2e-4, 'f32': 3e-3}[precision], frac_mismatch
     print(f'cfg {cfg_i} {precision}: max obs err {stats["max_err"]:.3e}, env-steps with a flag mismatch {frac_mismatch:.2e} '
           f'(below margin: {stats["unsafe"] / stats["total"]:.2e})')
+    record_metric(f'step_reset_vs_oracle[cfg{cfg_i}-{precision}]', max_obs_err=stats['max_err'], tol=tol, frac_flag_mismatch=frac_mismatch,
+                  frac_below_margin=stats['unsafe'] / stats['total'], env_steps=stats['total'])
     genv.close()
 
 
@@ -359,6 +361,8 @@ def test_free_running_f32_follows_the_oracle_within_1e_4(gpr, oracle, M, n, E):
         worst = max(worst, float(err[alive].max(initial=0.0)))
         n_steps += int(alive.sum()); n_resets += int((o['terminated'] | o['truncated'])[alive].sum())
     assert alive.mean() > 0.99 and n_resets > E and worst < 1e-5, (alive.mean(), n_resets, worst)  # (measured: nobody leaves, worst 8e-7)
+    record_metric(f'free_running_f32[M{M}]', frac_envs_following_the_oracle=float(alive.mean()), max_obs_err=worst, tol=1e-4,
+                  env_steps_followed=n_steps, auto_resets_followed=n_resets)
     genv.close()
 
 
@@ -609,3 +613,47 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 2048
     assert c['rollout_flush']['env_steps_per_s'] > 0 and 0 < c['done_fraction_per_step'] < 0.5
     assert c['timed_seconds'] >= 0.02 and c['timed_steps'] % 30 == 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fixtures taken from the imported reference METHODS (tests/golden/make_golden.py, round 2): observation orderings (PL:536-573)
+# and the per-cycle control decision (PL:420-450), through the C ABI
+# ----------------------------------------------------------------------------------------------------------------------
+def _fixed_state_env(gpr, M, E, **kw):
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((6, 6)), M, num_envs=E, precision='f64', std_noise=0.0, autoreset_mode='disabled',
+                                      max_episode_steps=None, **kw)
+    env.reset(seed=0)
+    return env
+
+
+@pytest.mark.parametrize('mode', ['acc', 'jerk'])
+def test_obs_ordering_matches_reference_get_obs(gpr, mode):
+    z = load_npz('obs_ordering.npz')
+    for M in (1, 3, 4):
+        t = f'{mode}_M{M}'
+        env = _fixed_state_env(gpr, M, 1, learn_jerk=(mode == 'jerk'), num_cycles=0)
+        f = lambda k: torch.as_tensor(z[f'{t}_{k}'].reshape(1, -1), device=env.device)  # noqa: E731
+        env.pos.copy_(f('pos')); env.vel.copy_(f('vel')); env.acc.copy_(f('acc')); env.goals.copy_(f('goals'))
+        obs, *_ = env.step(torch.zeros(1, 2 * M, dtype=env.dtype, device=env.device))
+        for k in ('observation', 'achieved_goal', 'desired_goal'):
+            assert np.array_equal(obs[k].cpu().numpy()[0], z[f'{t}_{k}']), (t, k)  # a num_cycles = 0 step only assembles the observation
+        env.close()
+
+
+@pytest.mark.parametrize('mode', ['acc', 'jerk'])
+def test_control_decision_matches_reference_step_callback(gpr, mode):
+    """one control cycle (num_cycles = 1): the ctrl the reference hands to MuJoCo, recovered from the state change of the step"""
+    z = load_npz('step_callback.npz')
+    vel, acc, act, ctrl = z[f'{mode}_vel'], z[f'{mode}_acc'], z[f'{mode}_action'], z[f'{mode}_ctrl']
+    n, M, dt = vel.shape[0], vel.shape[1], float(z['dt'])
+    env = _fixed_state_env(gpr, M, n, learn_jerk=(mode == 'jerk'), num_cycles=1)
+    pos = np.tile(np.array([[0.40, 0.40, 1.00, 1.00]]), (n, 1))
+    env.pos.copy_(torch.as_tensor(pos, device=env.device))
+    env.vel.copy_(torch.as_tensor(vel.reshape(n, -1), device=env.device)); env.acc.copy_(torch.as_tensor(acc.reshape(n, -1), device=env.device))
+    before = (env.acc if mode == 'jerk' else env.vel).clone()
+    env.step(torch.as_tensor(act, device=env.device))
+    got = (((env.acc if mode == 'jerk' else env.vel) - before) / dt).cpu().numpy().reshape(n, M, 2)  # act' = act + dt jerk / v' = v + dt acc
+    err = np.abs(got - ctrl).max()
+    record_metric(f'control_decision[{mode}]', max_ctrl_err=err, tol=1e-8 * (100.0 if mode == 'jerk' else 10.0))
+    assert err < 1e-8 * (100.0 if mode == 'jerk' else 10.0), err
+    env.close()

@@ -161,3 +161,35 @@ def test_closed_form_trajectories(oracle, storage_f32):
         assert np.allclose(pos, z[f'{i}_pos']) and np.allclose(vel, z[f'{i}_vel']) and np.allclose(acc, z[f'{i}_acc']), i
         assert np.abs(pos - z[f'{i}_pos']).max() < 1e-12 and np.abs(vel - z[f'{i}_vel']).max() < 1e-13, i
         assert np.abs(acc - z[f'{i}_acc']).max() < 1e-10, i
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 2: observation orderings (PL:536-573) and the per-cycle control decision (PL:420-450), from the reference's methods
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['acc', 'jerk'])
+def test_obs_ordering(oracle, mode):
+    z = load_npz('obs_ordering.npz')
+    for M in (1, 3, 4):
+        t = f'{mode}_M{M}'
+        env = oracle.OraclePlanningEnv(np.ones((6, 6)), M, 1, std_noise=0.0, num_cycles=0, learn_jerk=(mode == 'jerk'), autoreset='disabled',
+                                       max_episode_steps=None)
+        env.pos[:] = z[f'{t}_pos'].reshape(1, -1); env.vel[:] = z[f'{t}_vel'].reshape(1, -1)
+        env.acc[:] = z[f'{t}_acc'].reshape(1, -1); env.goal[:] = z[f'{t}_goals'].reshape(1, -1)
+        o = env.step(np.zeros((1, 2 * M)))
+        for k in ('observation', 'achieved_goal', 'desired_goal'):
+            assert np.array_equal(o[k][0], z[f'{t}_{k}']), (t, k)
+
+
+@pytest.mark.parametrize('mode', ['acc', 'jerk'])
+def test_control_decision(oracle, mode):
+    z = load_npz('step_callback.npz')
+    vel, acc, act, ctrl = z[f'{mode}_vel'], z[f'{mode}_acc'], z[f'{mode}_action'], z[f'{mode}_ctrl']
+    n, M, dt = vel.shape[0], vel.shape[1], float(z['dt'])
+    env = oracle.OraclePlanningEnv(np.ones((6, 6)), M, n, std_noise=0.0, num_cycles=1, learn_jerk=(mode == 'jerk'), autoreset='disabled',
+                                   max_episode_steps=None)
+    env.pos[:] = np.array([0.40, 0.40, 1.00, 1.00]); env.vel[:] = vel.reshape(n, -1); env.acc[:] = acc.reshape(n, -1)
+    before = (env.acc if mode == 'jerk' else env.vel).copy()
+    env.step(act)
+    got = (((env.acc if mode == 'jerk' else env.vel) - before) / dt).reshape(n, M, 2)
+    assert np.abs(got - ctrl).max() < 1e-8 * (100.0 if mode == 'jerk' else 10.0)
+    assert (np.abs(ctrl.reshape(n, -1) - act).max(axis=1) > 1e-9).mean() > 0.4  # the fixture really exercises the clamps
