@@ -23,8 +23,9 @@ flush is ONE all_reduce of the six episode counters (48 bytes), timed as config.
 
 Workload (BASELINE.json): BenchmarkPlanningEnv, 4 movers, layout ones(6,6), reference defaults
 (num_cycles 40, dt 1e-3, v_max 2, a_max 10, circle r 0.11, std_noise 1e-5, TimeLimit 50), actions ~ U(-a_max, a_max).
-Extras in `config` (never `value`): sigma = 0; larger batches (262 144 and 1 048 576 envs); the reference's dtype
-(f64 and f32 storage / f64 arithmetic).
+Extras in `config` (never `value`): sigma = 0; other batch sizes (4 096, 262 144 and 1 048 576 envs); the reference's dtype
+(f64 and f32 storage / f64 arithmetic); open-loop rollouts with 50 env-steps per launch (gpr_step_n) at 65 536 envs and at the
+8 192-envs-per-GPU shard of the strong-scaling shape.
 """
 from __future__ import annotations
 
@@ -194,6 +195,54 @@ def timed(args, rank, local_rank, world, steps=None, warmup=None, **kw):
     return res
 
 
+def timed_rollout_launch(args, rank, local_rank, world, envs, n_steps=T_ROLLOUT):
+    """open-loop rollouts through gpr_step_n: n_steps env-steps per kernel launch (same work per step, same results bit for bit)"""
+    import numpy as np
+    import torch
+
+    import gymnasium_planar_robotics_amd as gpr
+
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((args.tiles, args.tiles)), args.movers, num_envs=envs, device=device, std_noise=1e-5,
+                                      precision=args.precision, env_id_offset=rank * envs)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    acts = (torch.rand(n_steps, envs, 2 * args.movers, device=device, generator=gen, dtype=torch.float32) * (2 * env.a_max) - env.a_max).to(env.dtype)
+    roll = env.alloc_rollout(n_steps)
+    env.reset(seed=0)
+    env.elapsed_steps.copy_(torch.randint(0, T_ROLLOUT, (envs,), device=device, generator=gen, dtype=torch.int32))
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    launches = 2
+    with torch.cuda.device(device):
+        env.step_n(acts, roll)
+        for _ in range(6):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(launches):
+                env.step_n(acts, roll)
+            sync()
+            wall = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+                w = torch.tensor([wall], device=device, dtype=torch.float64)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                wall = float(w.item())
+            if wall >= args.min_seconds:
+                break
+            launches = int(math.ceil(launches * args.min_seconds / max(wall, 1e-6) * 1.25))
+    env.close()
+    n = launches * n_steps
+    return {'what': f'gpr_step_n: {n_steps} env-steps per kernel launch (open-loop actions; outputs identical to {n_steps} step() calls)',
+            'envs_per_gpu': envs, 'env_steps_per_s': world * envs * n / wall, 'us_per_step': wall / n * 1e6}
+
+
 def cpu_baseline(args):
     """The oracle (plain-C port of the reference semantics, fp64) on this box's host cores: a bounded sample of the same workload."""
     import numpy as np
@@ -280,7 +329,8 @@ def main():
             Es = max(1, args.envs_per_gpu // world)
             st = timed(args, rank, local_rank, world, envs=Es)
             cfg['strong_scaling'] = {'envs_total': Es * world, 'envs_per_gpu': Es, 'env_steps_per_s': st['env_steps_per_s'],
-                                     'ms_per_step': st['wall'] / st['n_steps'] * 1e3, 'kernel_us': st['kernel_us']}
+                                     'ms_per_step': st['wall'] / st['n_steps'] * 1e3, 'kernel_us': st['kernel_us'],
+                                     'rollout_launch': timed_rollout_launch(args, rank, local_rank, world, Es)}
 
             def flush_counters(p):
                 p.env.all_reduce_episode_counters()  # ONE all_reduce of six uint64 counters; rollouts stay sharded
@@ -297,6 +347,7 @@ def main():
                 sizes[str(n)] = {'env_steps_per_s': r['env_steps_per_s'], 'kernel_us': r['kernel_us'],
                                  'hbm_frac': B * n / (r['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
             cfg['other_batch_sizes'] = sizes
+            cfg['rollout_launch'] = {str(n): timed_rollout_launch(args, rank, local_rank, world, n) for n in (8192, E)}
             if args.precision == 'f32':
                 prec = {}
                 for pr in ('f32_f64acc', 'f64'):

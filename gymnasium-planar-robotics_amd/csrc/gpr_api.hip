@@ -201,6 +201,7 @@ KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
     P.pos = e->state.pos_dev; P.vel = e->state.vel_dev; P.acc = e->state.acc_dev; P.goal = e->state.goal_dev;
     P.elapsed = e->state.elapsed_dev;
     P.counters = e->counters_on ? e->counters : nullptr;
+    P.n_steps = 1;
     if (out) {
         P.obs = out->observation_dev; P.ag = out->achieved_goal_dev; P.dg = out->desired_goal_dev; P.reward = out->reward_dev;
         P.terminated = out->terminated_dev; P.truncated = out->truncated_dev; P.is_success = out->is_success_dev;
@@ -453,6 +454,27 @@ int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void
     P.action = action_dev;
     rc = launch_env(env, false, P, as_stream(hip_stream));
     if (rc == GPR_OK) env->tick += 1;
+    return rc;
+}
+
+int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_step_out *out, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_step_n: NULL handle");
+    if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_step_n: call gpr_bind_state first");
+    if (!action_dev || n_steps < 1) return fail(env, GPR_E_INVALID, "gpr_step_n: action is NULL or n_steps < 1");
+    if (env->cfg.autoreset_mode == GPR_AUTORESET_DISABLED && n_steps > 1)
+        return fail(env, GPR_E_INVALID, "gpr_step_n: several steps per launch need an autoreset mode (a finished env must go on)");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    if (out->desired_goal_dev == env->state.goal_dev && n_steps > 1)
+        return fail(env, GPR_E_INVALID, "gpr_step_n: desired_goal must not alias the goal state (every step keeps its own)");
+    KParams P = make_params(env, out, false);
+    P.action = action_dev;
+    const int64_t E = env->cfg.num_envs, M = env->cfg.num_movers;
+    const int64_t sz = env->cfg.precision == GPR_PRECISION_F64 ? 8 : 4, obs_dim = 2 * M * (env->cfg.learn_jerk ? 2 : 1);
+    P.n_steps = n_steps;
+    P.ss_action = E * 2 * M * sz; P.ss_obs = E * obs_dim * sz; P.ss_goal = E * 2 * M * sz; P.ss_reward = E * sz; P.ss_flag = E;
+    rc = launch_env(env, false, P, as_stream(hip_stream));
+    if (rc == GPR_OK) env->tick += (uint64_t)n_steps;
     return rc;
 }
 

@@ -53,6 +53,8 @@ struct KParams {
     void *obs, *ag, *dg, *reward;
     uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
     void *final_obs, *final_ag, *final_dg;
+    int32_t n_steps;            // gpr_step_n: env-steps per launch (1: gpr_step) and the byte strides from one step's tensors to the next's
+    int64_t ss_action, ss_obs, ss_goal, ss_reward, ss_flag;
     uint32_t *counters;         // [wavefronts][6] episode counters (include/gpr.h: GPR_CNT_*), NULL = not counting
     unsigned int *wave_timing;  // debug builds (-DGPR_WAVE_TIMING): 8 words per wavefront of the step kernel, else NULL
 };
@@ -642,6 +644,20 @@ template <typename RT, int LPE, int D> struct BoxNear {
             const bool n = (absr(dx) <= sx) & (absr(dy) <= sy);
             if constexpr (D < LPE / 2) return n | BoxNear<RT, LPE, D + 1>::run(x, y, sx, sy);
             else return n;
+        }
+    }
+};
+// the same as ONE number per lane: the smallest over the partners of max(|dx| - sx, |dy| - sy); <= 0 iff BoxNear holds
+template <typename RT, int LPE, int D> struct BoxNearMetric {
+    static __device__ __forceinline__ RT run(RT x, RT y, RT sx, RT sy) {
+        if constexpr (LPE == 1) {
+            return Math<RT>::inf();
+        } else {
+            RT dx, dy;
+            rot_diff2<LPE, D>(x, y, dx, dy);
+            const RT m = fmax(absr(dx) - sx, absr(dy) - sy);
+            if constexpr (D < LPE / 2) return fmin(m, BoxNearMetric<RT, LPE, D + 1>::run(x, y, sx, sy));
+            else return m;
         }
     }
 };

@@ -219,8 +219,33 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 // -----------------------------------------------------------------------------------------------------------------
 // step
 // -----------------------------------------------------------------------------------------------------------------
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI>
+__device__ __forceinline__ void step_body(const KParams &P0) {
+    // gpr_step_n: n_steps env-steps in ONE launch (actions and outputs [n][E][.]). Every block walks through its envs' steps on its
+    // own: no launch, no grid-wide drain and no simultaneous load burst of the whole batch between two steps; what a block's
+    // wavefronts exchange (the resets they serve for each other) crosses a block barrier. Step i uses the call counter tick + i,
+    // so the n steps are bit for bit the n calls of gpr_step.
+    // (MULTI = false, gpr_step: P IS the kernel argument segment; the per-step copy below costs the multi-step kernels registers)
+    for (int st = 0; st < (MULTI ? P0.n_steps : 1); ++st) {
+    KParams Pm;
+    if constexpr (MULTI) Pm = P0;
+    KParams &P = MULTI ? Pm : const_cast<KParams &>(P0);
+    if (MULTI && st > 0) {
+        const int64_t k = st;
+        P.action = static_cast<const char *>(P0.action) + k * P0.ss_action;
+        P.obs = static_cast<char *>(P0.obs) + k * P0.ss_obs; P.ag = static_cast<char *>(P0.ag) + k * P0.ss_goal;
+        if (P0.dg != P0.goal) P.dg = static_cast<char *>(P0.dg) + k * P0.ss_goal;
+        P.reward = static_cast<char *>(P0.reward) + k * P0.ss_reward;
+        P.terminated = P0.terminated + k * P0.ss_flag; P.truncated = P0.truncated + k * P0.ss_flag; P.is_success = P0.is_success + k * P0.ss_flag;
+        P.mover_collision = P0.mover_collision + k * P0.ss_flag; P.wall_collision = P0.wall_collision + k * P0.ss_flag;
+        if (P0.final_obs != nullptr) {
+            P.final_obs = static_cast<char *>(P0.final_obs) + k * P0.ss_obs; P.final_ag = static_cast<char *>(P0.final_ag) + k * P0.ss_goal;
+            P.final_dg = static_cast<char *>(P0.final_dg) + k * P0.ss_goal;
+        }
+        const uint64_t tick = (((uint64_t)P0.tick_hi << 32) | P0.tick_lo) + (uint64_t)st;
+        P.tick_lo = (uint32_t)tick; P.tick_hi = (uint32_t)(tick >> 32);
+        __syncthreads();  // the previous step's stores and served resets of this block are complete and visible
+    }
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
@@ -554,21 +579,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         }
     };
 
-    // BLOCKS OF KB CYCLES, CHECKED AFTERWARDS (grids without holes, circles). A SIMD of this machine retires a plain vector
-    // instruction every ~2.5 clocks and a packed one every ~5 with the four wavefronts this workload gives it, and every
-    // wave-level decision (v_cmp -> SGPR -> s_cbranch) stalls its wavefront for 40-60 clocks (scratch/ubench/simd.hip,
-    // cycle.hip). So a block of KB cycles runs straight-line: integrate, wall reach and pair sweep of every cycle, each
-    // cycle's state and reaches kept in registers, the closest approach to a wall / to another mover as a running max / min --
-    // and ONE decision at the block's end: did anything come within the noise band of a threshold? If not (the common case) the
-    // block is done. If so, the flagged cycles are looked at in order, each with exact_cycle's noisy tests on the state saved
-    // for that cycle; an env that collides is rolled back to the state of its colliding cycle (BE:1904-1905) and taken out,
-    // which also takes it out of the tests of the block's later cycles. Same operations in the same order as the
-    // cycle-by-cycle path, so the results are bit-identical to it (GPR_EAGER_NOISE=1 runs only exact_cycle; tests compare).
-    // The speed clamp: lanes that may reach the limit inside the block (the rung test of the cycle-by-cycle ladder) make the
-    // wavefront run the block's clamp form, in which every lane evaluates PL:634-643 branch-free on its reading from LDS
-    // (lanes without a row read zeros and cannot clamp).
-    GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
-    // BLOCKS OF KB CYCLES, CHECKED AFTERWARDS (grids without holes, circles). A SIMD of this machine retires a plain vector
+    // BLOCKS OF KB CYCLES, CHECKED AFTERWARDS (grids without holes; circles, and boxes through their axis-aligned pre-tests). A SIMD of this machine retires a plain vector
     // instruction every ~2.5 clocks and a packed one every ~5 with the four wavefronts this workload gives it, and every
     // wave-level decision (v_cmp -> SGPR -> s_cbranch) stalls its wavefront for 40-60 clocks (scratch/ubench/simd.hip,
     // cycle.hip). So a block of KB cycles runs straight-line: integrate, wall reach and pair sweep of every cycle, each
@@ -584,7 +595,13 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
     constexpr int KB = 4;
     static_assert(KC1 == KB - 1, "the first rung covers exactly one block");
-    const bool fast_ok = FULL && SHAPE == 0 && !every;
+    const bool fast_ok = FULL && !every;
+    // the block's pair pre-test per cycle, ONE number per lane: circles: the smallest squared pair distance (near iff <= p0r); boxes:
+    // the smallest over the partners of max(|dx| - bnx, |dy| - bny) (near iff <= 0: some partner's inflated bounding box overlaps)
+    auto pair_reach = [&](RT qx, RT qy) -> RT {
+        if constexpr (SHAPE == 0) return pair_min_dist<RT, LPE>(qx, qy);
+        else return BoxNearMetric<RT, LPE, 1>::run(qx, qy, bnx, bny);
+    };
     for (int cyc = 0; cyc < P.num_cycles;) {  // BE:1879
         int n_exact = P.num_cycles - cyc;
         if (fast_ok & (cyc + KB <= P.num_cycles)) {
@@ -604,6 +621,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 R2<RT> dps[KB], dvs[KB];
                 RT es[KB], ms[KB];
                 RT eacc = -INF, macc = INF;
+                const R2<RT> dp_b = dp, dv_b = dv;  // (box shape: a flagged block is replayed cycle by cycle from here)
                 if (needy == 0ull) {
 #pragma unroll
                     for (int j = 0; j < KB; ++j) {
@@ -613,7 +631,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                         es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
                         eacc = __builtin_fmaxf(eacc, es[j]);
                         ms[j] = INF;
-                        if constexpr (LPE > 1) { ms[j] = pair_min_dist<RT, LPE>(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                        if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
                     }
                 } else {
                     GPR_WT(wt_clamp += KB;)
@@ -633,18 +651,30 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                         es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
                         eacc = __builtin_fmaxf(eacc, es[j]);
                         ms[j] = INF;
-                        if constexpr (LPE > 1) { ms[j] = pair_min_dist<RT, LPE>(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                        if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
                     }
                 }
-                if ((__ballot(!(eacc < w0)) | __ballot(macc <= p0r)) != 0ull) {
+                // (the near limit of a lane that is out -- dead, padding, frozen -- is -1: never reached; bnx is its flag for boxes)
+                const bool flagged = (__ballot(!(eacc < w0)) | __ballot(macc <= (SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1)))) != 0ull;
+                if (SHAPE == 1 && flagged) {
+                    // box shape: the exact rectangle tests (rotated vertices, table walk, 16 segment pairs per rectangle pair) are
+                    // long; instead of one copy of them per cycle of the block, the block is taken back and replayed through
+                    // exact_cycle (ONE copy, in the loop below)
+                    GPR_WT(++wt_near;)
+                    dp = dp_b; dv = dv_b;
+                    v.x = v0.x + dv.x; v.y = v0.y + dv.y;
+                } else {
+                if (flagged) {
                     GPR_WT(++wt_near;)
 #pragma unroll
                     for (int j = 0; j < KB; ++j) {
                         // (w0 / p0r / wx_l / pthr_l of an env that collided in an earlier cycle of this block are +inf / -1 by now)
-                        if ((__ballot(!(es[j] < w0)) | __ballot(ms[j] <= p0r)) == 0ull) continue;
+                        const RT pnj = SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1);
+                        if ((__ballot(!(es[j] < w0)) | __ballot(ms[j] <= pnj)) == 0ull) continue;
                         GPR_WT(++wt_exact;)
                         const R2<RT> pj{p0.x + dps[j].x, p0.y + dps[j].y};
                         unsigned long long wraw = __ballot(!(es[j] < wx_l)), hraw = 0ull;
+                        {
                         if constexpr (NOISE) {
                             if (__ballot(!(__builtin_fabsf(wx_l - es[j]) > wband)) != 0ull) {
                                 const R2<RT> pw = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u));
@@ -659,6 +689,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                                     hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
                                 }
                             }
+                        }
                         }
                         if ((wraw | hraw) != 0ull) {  // BE:1904-1905: the env stops in this cycle
                             wc_m |= wraw;
@@ -676,6 +707,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
                 }
                 cyc += KB;
                 continue;
+                }
             }
             n_exact = KB;
         }
@@ -850,7 +882,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         return nf;
     };
     int cyc = 0;
-    if constexpr (Math<RT>::literal && FULL && SHAPE == 0 && !JERK) {
+    if constexpr (Math<RT>::literal && FULL && SHAPE == 0) {
         // PARITY MODE ON A GRID WITHOUT HOLES: the reference's arithmetic, but its checks only where they can matter. The state
         // advances in double exactly as above (v += dt a; p += dt v, the same operations in the same order). Whether a cycle
         // needs the literal wall / pair checks at all is decided in FLOAT on a float copy of the position: on a full grid with
@@ -859,7 +891,8 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
         // than noise band + float slack is valid for every possible read, and the literal tests -- table look-ups, tile-edge
         // uncertainty, double-precision Box-Muller draws -- are evaluated only in the flagged cycles, on the double state saved
         // for them. Blocks of KB cycles, one decision per block, as in the throughput loop; cycles in which a lane may reach
-        // the speed limit go through advance() one by one (its clamp is a sqrt and four divisions in double).
+        // the speed limit go through advance() one by one (its clamp is a sqrt and four divisions in double) -- and so does
+        // every cycle of jerk mode (two clamps per cycle, PL:432-440), which still skips the literal checks of unflagged cycles.
         constexpr int KB = 4;
         const float INFf = __builtin_huge_valf();
         const float cxf = (float)((RT)0.5 * (C.gx0 + C.gx1)), cyf = (float)((RT)0.5 * (C.gy0 + C.gy1));
@@ -891,9 +924,9 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
             }
         };
         while (cyc + KB <= P.num_cycles) {
-            if (cyc + KB - 1 >= next_c) {
+            if (JERK | (cyc + KB - 1 >= next_c)) {
                 const RT t0 = v.x + dta_d.x, t1 = v.y + dta_d.y, n2 = t0 * t0 + t1 * t1;
-                if (__ballot(!(n2 < r1)) != 0ull) {
+                if (JERK | (__ballot(!(n2 < r1)) != 0ull)) {
                     // some lane may clamp within this block: its cycles one by one (advance() decides about readings and clamp)
                     for (int j = 0; j < KB; ++j, ++cyc) {
                         advance(cyc);
@@ -1055,8 +1088,13 @@ __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
     }
 #endif
 #undef GPR_WT
+    }  // for st
 }
 
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI>
+__global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
+    step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, MULTI>(P);
+}
 // -----------------------------------------------------------------------------------------------------------------
 // reset (explicit): BE:1770-1833 for the envs selected by mask (all when mask == NULL)
 // -----------------------------------------------------------------------------------------------------------------
@@ -1103,11 +1141,12 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     // the tile tables of a large layout (64 x 64 cells in f64: 47 KB) plus the kernels' static LDS exceed the 64 KB a launch
     // gets by default: raise the kernel's limit once (gfx950 has 160 KB per CU; gpr_create bounds the table size)
     if (lds > 32u * 1024u) {
-        static bool raised_reset = false, raised_step = false;
-        bool &raised = is_reset ? raised_reset : raised_step;
+        static bool raised_reset = false, raised_step = false, raised_multi = false;
+        bool &raised = is_reset ? raised_reset : (P.n_steps > 1 ? raised_multi : raised_step);
         if (!raised) {
             const void *fn = is_reset ? reinterpret_cast<const void *>(&k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
-                                      : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>);
+                                      : (P.n_steps > 1 ? reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>)
+                                                       : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>));
             const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
             if (he != hipSuccess) return he;
             raised = true;
@@ -1115,8 +1154,10 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     }
     if (is_reset) {
         hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
+    } else if (P.n_steps > 1) {
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>), dim3(grid), dim3(BLOCK), lds, s, P);
     } else {
-        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>), dim3(grid), dim3(BLOCK), lds, s, P);
     }
     return hipGetLastError();
 }
@@ -1129,9 +1170,7 @@ template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipEr
     }
     // grids without holes: the throughput-mode wall check has a table-free form (pos_valid_circle), and the parity-mode step
     // loop evaluates its literal checks only near the outer walls (acceleration actions): separate kernels
-    if constexpr (!Math<RT>::literal || !JERK) {
-        if (P.layout_full && (!Math<RT>::literal || !is_reset)) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 0>(is_reset, P, s);
-    }
+    if (P.layout_full && (!Math<RT>::literal || !is_reset)) return launch_kernel<ST, RT, LPE, JERK, NOISE, true, 0>(is_reset, P, s);
     return launch_kernel<ST, RT, LPE, JERK, NOISE, false, 0>(is_reset, P, s);
 }
 template <typename ST, typename RT, int LPE> static hipError_t launch_flags(bool is_reset, const KParams &P, hipStream_t s) {

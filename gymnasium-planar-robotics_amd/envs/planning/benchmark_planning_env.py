@@ -234,6 +234,37 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         assert tuple(action.shape) == (self.num_envs, 2 * self.num_movers), 'action dim != action_space dim'
         _native.check(self._lib.gpr_step(self._handle, action.data_ptr(), C.byref(out), self._stream()), self._handle)
 
+    # ------------------------------------------------------------------------------------------------------------
+    # open-loop rollouts: n env-steps per kernel launch (gpr_step_n)
+    # ------------------------------------------------------------------------------------------------------------
+    def alloc_rollout(self, n_steps: int) -> dict[str, torch.Tensor]:
+        """[n_steps, num_envs, ...] tensors for everything ``step()`` returns (observation dict, reward, terminated, truncated, the
+        three info flags and, with same-step autoreset, the terminal observations), to be filled by ``step_n``."""
+        E, M, dev, dt, T = self.num_envs, self.num_movers, self.device, self.dtype, int(n_steps)
+        z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        r = dict(observation=z(T, E, self.obs_dim), achieved_goal=z(T, E, 2 * M), desired_goal=z(T, E, 2 * M), reward=z(T, E))
+        for k in ('terminated', 'truncated', 'is_success', 'mover_collision', 'wall_collision'):
+            r[k] = z(T, E, dtype=torch.uint8)
+        if self.autoreset_mode == 'same_step':
+            r.update(final_observation=z(T, E, self.obs_dim), final_achieved_goal=z(T, E, 2 * M), final_desired_goal=z(T, E, 2 * M))
+        fin = (lambda k: r[k].data_ptr()) if self.autoreset_mode == 'same_step' else (lambda k: None)  # noqa: E731
+        r['_out'] = _native.GprStepOut(r['observation'].data_ptr(), r['achieved_goal'].data_ptr(), r['desired_goal'].data_ptr(), r['reward'].data_ptr(),
+                                       r['terminated'].data_ptr(), r['truncated'].data_ptr(), r['is_success'].data_ptr(),
+                                       r['mover_collision'].data_ptr(), r['wall_collision'].data_ptr(), fin('final_observation'),
+                                       fin('final_achieved_goal'), fin('final_desired_goal'))
+        return r
+
+    def step_n(self, actions: torch.Tensor, rollout: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        """``actions.shape[0]`` env-steps in ONE kernel launch (open-loop: random, scripted or replayed actions): row ``i`` of every
+        tensor of ``rollout`` (from ``alloc_rollout``) receives what the ``i``-th ``step(actions[i])`` returns, bit for bit. Every
+        block of the kernel walks through its envs' steps on its own, so the per-step launch, drain and load burst disappear."""
+        T = int(actions.shape[0])
+        assert actions.dtype == self.dtype and actions.device == self.device and actions.is_contiguous()
+        assert tuple(actions.shape) == (T, self.num_envs, 2 * self.num_movers) and rollout['reward'].shape[0] == T
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.gpr_step_n(self._handle, T, actions.data_ptr(), C.byref(rollout['_out']), self._stream()), self._handle)
+        return rollout
+
     def compute_reward(self, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, info: dict[str, torch.Tensor]) -> torch.Tensor:
         """Batched HER reward (PL:502-534). ``info`` holds 'mover_collision' and 'wall_collision' tensors of shape (batch,)."""
         return self._reward_and_terminated(achieved_goal, desired_goal, info)[0]

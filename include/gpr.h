@@ -118,6 +118,12 @@ int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, vo
 /* step(action) (BE:1835-1950 + PL:420-450 + TimeLimit). action_dev: [E][2M] real, clipped to the action space. */
 int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
 
+/* n_steps env-steps in ONE launch, for open-loop rollouts (random / scripted / replayed actions; the benchmark's rollouts): what
+ * n_steps calls of gpr_step do, bit for bit (step i draws from call counter tick + i), without a launch, a grid-wide drain and a
+ * whole-batch load burst between two steps. action_dev is [n_steps][E][2M] real; EVERY tensor of `out` (final_* included, if set)
+ * is [n_steps][E][...], contiguous: row i holds what the i-th gpr_step would have returned. Needs an autoreset mode. */
+int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_step_out *out, void *hip_stream);
+
 /* Episode counters (engine addition, SURVEY.md section 5: the reference logs nothing). Every step kernel adds, per wavefront,
  * the popcounts of its done masks to a small device table owned by the handle; gpr_read_counters sums that table into the
  * caller's six uint64 totals (added to what is there), and clears the table. Counting starts with the first

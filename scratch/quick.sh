@@ -9,4 +9,5 @@ d=json.loads(sys.stdin.read()); c=d['config']
 print('value %.4g  kernel_us %.2f  sigma0_us %.2f  done_frac %.3f' % (d['value'], d['roofline']['kernel_us'], c.get('sigma0_kernel_us', -1), c['done_fraction_per_step']))
 for k in ('other_batch_sizes','reference_dtype'):
     for n,v in c.get(k,{}).items(): print('  %s %s: %.2f us  %.4g env-steps/s  hbm %.3f' % (k, n, v['kernel_us'], v['env_steps_per_s'], v['hbm_frac']))
+for n,v in c.get('rollout_launch',{}).items(): print('  rollout_launch %s: %.2f us/step  %.4g env-steps/s' % (n, v['us_per_step'], v['env_steps_per_s']))
 "

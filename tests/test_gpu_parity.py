@@ -611,6 +611,7 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 30
     c = line['config']
     assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 2048
+    assert c['strong_scaling']['rollout_launch']['env_steps_per_s'] > 0
     assert c['rollout_flush']['env_steps_per_s'] > 0 and 0 < c['done_fraction_per_step'] < 0.5
     assert c['timed_seconds'] >= 0.02 and c['timed_steps'] % 30 == 0
 
@@ -657,3 +658,36 @@ def test_control_decision_matches_reference_step_callback(gpr, mode):
     record_metric(f'control_decision[{mode}]', max_ctrl_err=err, tol=1e-8 * (100.0 if mode == 'jerk' else 10.0))
     assert err < 1e-8 * (100.0 if mode == 'jerk' else 10.0), err
     env.close()
+
+
+@pytest.mark.parametrize('M,n,E,kw', [(4, 6, 20000, {}), (4, 6, 3000, {'autoreset_mode': 'next_step'}), (16, 10, 1500, {}),
+                                      (4, 6, 3000, {'precision': 'f64'}), (3, 5, 2000, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775])}})])
+def test_step_n_equals_n_steps(gpr, M, n, E, kw):
+    """gpr_step_n (T steps in one launch, every block walking through its steps alone) returns bit for bit what T calls of
+    gpr_step return: every output row, the final state, the position of the random streams"""
+    T = 57  # past the TimeLimit: truncations, collisions and auto-resets inside the launch
+    lay = np.ones((n, n))
+    a = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E, **kw); b = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E, **kw)
+    a.reset(seed=6); b.reset(seed=6)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    acts = (torch.rand(T, E, 2 * M, device='cuda', generator=g) * 20 - 10).to(a.dtype)
+    acts[:, : E // 4] *= 0.02  # (some envs live to the TimeLimit)
+    roll = b.step_n(acts, b.alloc_rollout(T))
+    n_done = 0
+    for t in range(T):
+        obs, rew, term, trunc, info = a.step(acts[t])
+        for k in ('observation', 'achieved_goal', 'desired_goal'):
+            assert torch.equal(obs[k], roll[k][t]), (t, k)
+        assert torch.equal(rew, roll['reward'][t]) and torch.equal(term, roll['terminated'][t].bool()) and torch.equal(trunc, roll['truncated'][t].bool())
+        for k in ('is_success', 'mover_collision', 'wall_collision'):
+            assert torch.equal(info[k], roll[k][t].bool()), (t, k)
+        done = term | trunc
+        n_done += int(done.sum())
+        if a.autoreset_mode == 'same_step' and bool(done.any()):
+            for k in ('observation', 'achieved_goal', 'desired_goal'):
+                assert torch.equal(info['final_obs'][k][done], roll['final_' + k][t][done]), (t, k)
+    assert n_done > E // 2
+    for k in ('pos', 'vel', 'goals', 'elapsed_steps'):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert a.get_rng_state() == b.get_rng_state()
+    a.close(); b.close()
