@@ -18,7 +18,7 @@ struct Rec { unsigned hw_id, xcc_id; long long t0, t1; };
 // KIND: 0 one dependent v_fma chain, 1 two chains, 2 four chains, 3 eight chains, 4 one dependent v_pk_fma chain,
 //       5 two v_pk_fma chains, 6 four v_pk_fma chains, 7 dependent v_add with DPP source (quad_perm) + s_nop 1
 //       8 v_cmp -> vcc -> s_cbranch (not taken) + 6 dependent fma, 9 same 7 VALU without the decision
-//       10 two-chain version of 8 (12 fma behind ONE decision), 11 v_cmp -> s_or -> s_cselect (no branch) + 6 fma
+//       (the cost of scalar-only decisions and branch-free selects: branch.hip)
 template <int KIND> __global__ void __launch_bounds__(256) k(float *out, Rec *rec, int iters) {
     float a0 = threadIdx.x * 1e-3f + 1.f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b = 0.9999f, c = 0.5f, big = 1e30f;
@@ -61,16 +61,6 @@ template <int KIND> __global__ void __launch_bounds__(256) k(float *out, Rec *re
         } else if constexpr (KIND == 9) {
             asm volatile("v_cmp_gt_f32 vcc, %0, %3\n\t" REP4("v_fma_f32 %0, %0, %1, %2\n\t") "v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\t"
                          : "+v"(a0) : "v"(b), "v"(c), "v"(big) : "vcc");
-        } else if constexpr (KIND == 10) {
-            asm volatile("v_cmp_gt_f32 vcc, %0, %4\n\tv_cmp_gt_f32 s[40:41], %1, %4\n\ts_or_b64 vcc, vcc, s[40:41]\n\ts_cbranch_vccnz 1f\n\t"
-                         REP4("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\t") "v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\t"
-                         "v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\t1:\n\t"
-                         : "+v"(a0), "+v"(a1) : "v"(b), "v"(c), "v"(big) : "vcc", "s40", "s41");
-        } else if constexpr (KIND == 11) {
-            unsigned s;
-            asm volatile("v_cmp_gt_f32 vcc, %0, %4\n\ts_cmp_lg_u64 vcc, 0\n\ts_cselect_b32 %1, 1, 0\n\t" REP4("v_fma_f32 %0, %0, %2, %3\n\t") "v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %0, %0, %2, %3\n\t"
-                         : "+v"(a0), "=s"(s) : "v"(b), "v"(c), "v"(big) : "vcc", "scc");
-            a7 += (float)s;
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -129,8 +119,6 @@ int main(int argc, char **argv) {
             run<7>("s_nop 1 + v_sub_f32_dpp, 1 chain", 8, out, rec, block);
             run<9>("cmp + 6 fma (no decision)", 7, out, rec, block);
             run<8>("cmp + vcc branch n.t. + 6 fma", 7, out, rec, block);
-            run<10>("2 cmp + or + branch + 2x6 fma", 14, out, rec, block);
-            run<11>("cmp + s_cselect + 6 fma", 7, out, rec, block);
             continue;
         }
         run<0>("v_fma_f32, 1 chain", 8, out, rec, block);
@@ -144,8 +132,6 @@ int main(int argc, char **argv) {
         run<7>("s_nop 1 + v_sub_f32_dpp, 1 chain", 8, out, rec, block);
         run<9>("cmp + 6 fma (no decision)", 7, out, rec, block);
         run<8>("cmp + vcc branch n.t. + 6 fma", 7, out, rec, block);
-        run<10>("2 cmp + or + branch + 2x6 fma", 14, out, rec, block);
-        run<11>("cmp + s_cselect + 6 fma", 7, out, rec, block);
     }
     return 0;
 }
