@@ -239,8 +239,10 @@ def timed_rollout_launch(args, rank, local_rank, world, envs, n_steps=T_ROLLOUT)
             launches = int(math.ceil(launches * args.min_seconds / max(wall, 1e-6) * 1.25))
     env.close()
     n = launches * n_steps
+    us = wall / n * 1e6
     return {'what': f'gpr_step_n: {n_steps} env-steps per kernel launch (open-loop actions; outputs identical to {n_steps} step() calls)',
-            'envs_per_gpu': envs, 'env_steps_per_s': world * envs * n / wall, 'us_per_step': wall / n * 1e6}
+            'kernel': 'gpr::k_step_n<float, float, 4, false, true, true, 0>', 'envs_per_gpu': envs, 'env_steps_per_s': world * envs * n / wall,
+            'us_per_step': us, 'hbm_frac': algorithmic_bytes_per_env_step(args.movers) * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def cpu_baseline(args):

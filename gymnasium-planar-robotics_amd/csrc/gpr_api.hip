@@ -8,6 +8,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gpr.h"
@@ -38,6 +39,9 @@ struct gpr_env {
     int lpe = 1;
     bool push_ready = false;
     size_t wave_timing_words = 0;
+    KParams *step_params = nullptr;  // gpr_step_n: device array of per-step parameter blocks (grown on demand)
+    int step_params_cap = 0;
+    std::vector<KParams> step_params_host;
     uint32_t *counters = nullptr;  // [waves][GPR_NUM_COUNTERS] per-wavefront episode counters (gpr_enable_counters)
     size_t counter_rows = 0;
     bool counters_on = false;
@@ -375,6 +379,7 @@ void gpr_destroy(gpr_env *env) {
     }
 #endif
     if (env->counters) (void)hipFree(env->counters);
+    if (env->step_params) (void)hipFree(env->step_params);
     if (env->tab_f32.dev) (void)hipFree(env->tab_f32.dev);
     if (env->tab_f64.dev) (void)hipFree(env->tab_f64.dev);
     delete env;
@@ -469,10 +474,40 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
         return fail(env, GPR_E_INVALID, "gpr_step_n: desired_goal must not alias the goal state (every step keeps its own)");
     KParams P = make_params(env, out, false);
     P.action = action_dev;
+    if (n_steps == 1) {
+        rc = launch_env(env, false, P, as_stream(hip_stream));
+        if (rc == GPR_OK) env->tick += 1;
+        return rc;
+    }
     const int64_t E = env->cfg.num_envs, M = env->cfg.num_movers;
     const int64_t sz = env->cfg.precision == GPR_PRECISION_F64 ? 8 : 4, obs_dim = 2 * M * (env->cfg.learn_jerk ? 2 : 1);
+    const int64_t ss_action = E * 2 * M * sz, ss_obs = E * obs_dim * sz, ss_goal = E * 2 * M * sz, ss_reward = E * sz, ss_flag = E;
+    // one parameter block per step: row i of every tensor, call counter tick + i
+    if (env->step_params_cap < n_steps) {
+        if (env->step_params) (void)hipFree(env->step_params);
+        env->step_params = nullptr; env->step_params_cap = 0;
+        hipError_t he = hipMalloc(reinterpret_cast<void **>(&env->step_params), sizeof(KParams) * (size_t)n_steps);
+        if (he != hipSuccess) return fail_hip(env, he, "gpr_step_n: hipMalloc");
+        env->step_params_cap = n_steps;
+    }
+    env->step_params_host.assign((size_t)n_steps, P);
+    auto adv = [](auto *&ptr, int64_t bytes) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<uintptr_t>(ptr) + (uintptr_t)bytes); };
+    for (int i = 1; i < n_steps; ++i) {
+        KParams &Q = env->step_params_host[(size_t)i];
+        adv(Q.action, i * ss_action);
+        adv(Q.obs, i * ss_obs); adv(Q.ag, i * ss_goal); adv(Q.dg, i * ss_goal); adv(Q.reward, i * ss_reward);
+        adv(Q.terminated, i * ss_flag); adv(Q.truncated, i * ss_flag); adv(Q.is_success, i * ss_flag);
+        adv(Q.mover_collision, i * ss_flag); adv(Q.wall_collision, i * ss_flag);
+        if (Q.final_obs) { adv(Q.final_obs, i * ss_obs); adv(Q.final_ag, i * ss_goal); adv(Q.final_dg, i * ss_goal); }
+        const uint64_t tick = env->tick + (uint64_t)i;
+        Q.tick_lo = (uint32_t)tick; Q.tick_hi = (uint32_t)(tick >> 32);
+    }
+    // (stream-ordered behind the previous launch that read the array; hipMemcpyAsync stages pageable memory before it returns)
+    hipError_t he = hipMemcpyAsync(env->step_params, env->step_params_host.data(), sizeof(KParams) * (size_t)n_steps, hipMemcpyHostToDevice,
+                                   as_stream(hip_stream));
+    if (he != hipSuccess) return fail_hip(env, he, "gpr_step_n: parameter upload");
     P.n_steps = n_steps;
-    P.ss_action = E * 2 * M * sz; P.ss_obs = E * obs_dim * sz; P.ss_goal = E * 2 * M * sz; P.ss_reward = E * sz; P.ss_flag = E;
+    P.step_params = env->step_params;
     rc = launch_env(env, false, P, as_stream(hip_stream));
     if (rc == GPR_OK) env->tick += (uint64_t)n_steps;
     return rc;

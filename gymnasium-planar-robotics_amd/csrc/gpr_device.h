@@ -53,8 +53,8 @@ struct KParams {
     void *obs, *ag, *dg, *reward;
     uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
     void *final_obs, *final_ag, *final_dg;
-    int32_t n_steps;            // gpr_step_n: env-steps per launch (1: gpr_step) and the byte strides from one step's tensors to the next's
-    int64_t ss_action, ss_obs, ss_goal, ss_reward, ss_flag;
+    int32_t n_steps;            // gpr_step_n: env-steps per launch (1: gpr_step) ...
+    const struct KParams *step_params;  // ... and (host side only) the device array of the n per-step parameter blocks
     uint32_t *counters;         // [wavefronts][6] episode counters (include/gpr.h: GPR_CNT_*), NULL = not counting
     unsigned int *wave_timing;  // debug builds (-DGPR_WAVE_TIMING): 8 words per wavefront of the step kernel, else NULL
 };

@@ -219,33 +219,10 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 // -----------------------------------------------------------------------------------------------------------------
 // step
 // -----------------------------------------------------------------------------------------------------------------
+// One env-step of every env of the block. MULTI (gpr_step_n): the block calls it once per step with that step's parameter block
+// (`first`: the first step of the launch), wavefronts reset their own envs and never wait for each other.
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI>
-__device__ __forceinline__ void step_body(const KParams &P0) {
-    // gpr_step_n: n_steps env-steps in ONE launch (actions and outputs [n][E][.]). Every block walks through its envs' steps on its
-    // own: no launch, no grid-wide drain and no simultaneous load burst of the whole batch between two steps; what a block's
-    // wavefronts exchange (the resets they serve for each other) crosses a block barrier. Step i uses the call counter tick + i,
-    // so the n steps are bit for bit the n calls of gpr_step.
-    // (MULTI = false, gpr_step: P IS the kernel argument segment; the per-step copy below costs the multi-step kernels registers)
-    for (int st = 0; st < (MULTI ? P0.n_steps : 1); ++st) {
-    KParams Pm;
-    if constexpr (MULTI) Pm = P0;
-    KParams &P = MULTI ? Pm : const_cast<KParams &>(P0);
-    if (MULTI && st > 0) {
-        const int64_t k = st;
-        P.action = static_cast<const char *>(P0.action) + k * P0.ss_action;
-        P.obs = static_cast<char *>(P0.obs) + k * P0.ss_obs; P.ag = static_cast<char *>(P0.ag) + k * P0.ss_goal;
-        if (P0.dg != P0.goal) P.dg = static_cast<char *>(P0.dg) + k * P0.ss_goal;
-        P.reward = static_cast<char *>(P0.reward) + k * P0.ss_reward;
-        P.terminated = P0.terminated + k * P0.ss_flag; P.truncated = P0.truncated + k * P0.ss_flag; P.is_success = P0.is_success + k * P0.ss_flag;
-        P.mover_collision = P0.mover_collision + k * P0.ss_flag; P.wall_collision = P0.wall_collision + k * P0.ss_flag;
-        if (P0.final_obs != nullptr) {
-            P.final_obs = static_cast<char *>(P0.final_obs) + k * P0.ss_obs; P.final_ag = static_cast<char *>(P0.final_ag) + k * P0.ss_goal;
-            P.final_dg = static_cast<char *>(P0.final_dg) + k * P0.ss_goal;
-        }
-        const uint64_t tick = (((uint64_t)P0.tick_hi << 32) | P0.tick_lo) + (uint64_t)st;
-        P.tick_lo = (uint32_t)tick; P.tick_hi = (uint32_t)(tick >> 32);
-        __syncthreads();  // the previous step's stores and served resets of this block are complete and visible
-    }
+__device__ __forceinline__ void step_body(const KParams &P, bool first) {
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
@@ -274,14 +251,19 @@ __device__ __forceinline__ void step_body(const KParams &P0) {
     // (local env index * 2 + "reset only"), and every wavefront that is through with its own cycles serves the queue, so that
     // the resets of the block overlap with the cycles of its slowest wavefront (one that clamps in all 40 cycles takes twice
     // as long as a quiet one) instead of waiting for it. Entries: -1 = reserved but not written yet.
+    // (gpr_step_n, MULTI: no queue -- every wavefront resets its own envs at the end of each of its steps, so that wavefronts never
+    // wait for each other and a block needs no barrier between two steps)
     __shared__ int reset_count, reset_claimed, waves_through, reset_list[BLOCK];
-    reset_list[threadIdx.x] = -1;
-    if (threadIdx.x == 0) { reset_count = 0; reset_claimed = 0; waves_through = 0; }
+    if constexpr (!MULTI) {
+        reset_list[threadIdx.x] = -1;
+        if (threadIdx.x == 0) { reset_count = 0; reset_claimed = 0; waves_through = 0; }
+    }
     bool queued = false;
     auto enqueue = [&](bool reset_only) {
+        queued = true;
+        if constexpr (MULTI) return;
         const int slot = atomicAdd(&reset_count, 1);
         __hip_atomic_store(&reset_list[slot], (int)(envc - env_block_base) * 2 + (int)reset_only, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        queued = true;
     };
 
     // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
@@ -300,8 +282,11 @@ __device__ __forceinline__ void step_body(const KParams &P0) {
     const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
     const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
-    if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) stage_tables(lds, P.tables, P.table_bytes);  // (the box functions and the literal checks read the tables)
-    else __syncthreads();  // (reset_count is initialised)
+    if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) {  // (the box functions and the literal checks read the tables)
+        if (!MULTI || first) stage_tables(lds, P.tables, P.table_bytes);
+    } else if constexpr (!MULTI) {
+        __syncthreads();  // (reset_count is initialised)
+    }
     const Tables<RT> T = make_tables<RT>(lds, P);
     const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);  // BE:487, add_safety_offset=False
 
@@ -1028,6 +1013,52 @@ __device__ __forceinline__ void step_body(const KParams &P0) {
     constexpr int EPW = LPE >= 8 ? (64 / LPE >= 4 ? 64 / LPE / 4 : 1) : 64 / LPE;
     constexpr int GROUPS = 64 / LPE;
     GPR_WT(const long long wt1 = __builtin_amdgcn_s_memtime();)
+    // one claim: n envs, S lane groups each; lane group gi works for claim slot gi / S on env `renv`
+    auto serve = [&](int n, int S, bool have, int64_t renv, bool rfirst) __attribute__((always_inline)) {
+        const int gi = (int)(threadIdx.x & 63) / LPE;
+        const bool rlive = have & (mv < M);
+        R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+        bool rwc, rmc;
+        const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc);
+        if (rlive & ((gi & (S - 1)) == 0)) {  // one group of the env's set stores
+            const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
+            const R2<RT> zero{(RT)0, (RT)0};
+            store2<ST, RT>(P.pos, ridx, rp);
+            store2<ST, RT>(P.vel, ridx, zero);
+            if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
+            store2<ST, RT>(P.goal, ridx, rg);
+            store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
+            // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
+            if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
+        }
+        (void)n;
+    };
+    if constexpr (MULTI) {
+        // the wavefront's own envs that end in this step, EPW at a time, in env order
+        const int gi = (int)(threadIdx.x & 63) / LPE;
+        const int64_t env_w0 = (t - (int64_t)(threadIdx.x & 63)) / LPE;  // first env of this wavefront
+        unsigned long long todo = __ballot(need & (mv == 0));           // one bit per needy env: lane gi * LPE
+        const unsigned long long rf_m = __ballot(reset_first & (mv == 0));
+        while (todo != 0ull) {
+            int n = __popcll(todo);
+            n = n < EPW ? n : EPW;
+            int S = 1;
+            while (2 * S * n <= GROUPS) S *= 2;
+            const int eslot = gi / S;
+            int tgt = 0;  // the env group claim slot `eslot` stands for: the eslot-th needy group
+            unsigned long long mm = todo;
+            for (int r = 0; r < n; ++r) {
+                const int g = __builtin_ctzll(mm) / LPE;
+                if (eslot == r) tgt = g;
+                mm &= mm - 1ull;
+            }
+            todo = mm;
+            const bool have = eslot < n;
+            const bool rfirst = ((rf_m >> (tgt * LPE)) & 1ull) != 0ull;
+            GPR_WT(wt_served += n;)
+            serve(n, S, have, env_w0 + tgt, rfirst);
+        }
+    } else {
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
         int base = 0, n = 0;
@@ -1058,23 +1089,8 @@ __device__ __forceinline__ void step_body(const KParams &P0) {
         const bool have = eslot < n;
         int entry;
         do { entry = __hip_atomic_load(&reset_list[base + (have ? eslot : 0)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
-        const int64_t renv = env_block_base + (entry >> 1);
-        const bool rfirst = (entry & 1) != 0;
-        const bool rlive = have & (mv < M);
-        R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
-        bool rwc, rmc;
-        const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc);
-        if (rlive & ((gi & (S - 1)) == 0)) {  // one group of the env's set stores
-            const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
-            const R2<RT> zero{(RT)0, (RT)0};
-            store2<ST, RT>(P.pos, ridx, rp);
-            store2<ST, RT>(P.vel, ridx, zero);
-            if constexpr (JERK) store2<ST, RT>(P.acc, ridx, zero);
-            store2<ST, RT>(P.goal, ridx, rg);
-            store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
-            // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
-            if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
-        }
+        serve(n, S, have, env_block_base + (entry >> 1), (entry & 1) != 0);
+    }
     }
 #ifdef GPR_WAVE_TIMING
     if (P.wave_timing && (threadIdx.x & 63) == 0) {  // clocks: cycles + own stores | queue service incl. waiting; counts
@@ -1088,12 +1104,29 @@ __device__ __forceinline__ void step_body(const KParams &P0) {
     }
 #endif
 #undef GPR_WT
-    }  // for st
 }
 
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI>
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
 __global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
-    step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, MULTI>(P);
+    step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
+}
+// gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:
+// no launch, no grid-wide drain and no simultaneous load burst of the whole batch between two steps, and no barrier either (a
+// wavefront resets its own envs). Step i reads its parameter block -- output rows i, call counter tick + i -- from steps[i] in
+// device memory through scalar loads, exactly as gpr_step's kernel reads the kernel argument segment (a per-step copy in
+// registers cost 40 VGPRs and a wavefront per SIMD), so the n steps are bit for bit the n calls of gpr_step.
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
+__global__ void __launch_bounds__(BLOCK) k_step_n(const KParams *__restrict__ steps, int n_steps) {
+    for (int st = 0; st < n_steps; ++st) {
+        if (st > 0) {
+            // this wavefront's stores of the previous step (its envs' state, incl. the resets it made for them) are complete before
+            // it reads that state again; no other wavefront touches its envs
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>(steps[st], st == 0);
+    }
 }
 // -----------------------------------------------------------------------------------------------------------------
 // reset (explicit): BE:1770-1833 for the envs selected by mask (all when mask == NULL)
@@ -1145,8 +1178,8 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
         bool &raised = is_reset ? raised_reset : (P.n_steps > 1 ? raised_multi : raised_step);
         if (!raised) {
             const void *fn = is_reset ? reinterpret_cast<const void *>(&k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
-                                      : (P.n_steps > 1 ? reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>)
-                                                       : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>));
+                                      : (P.n_steps > 1 ? reinterpret_cast<const void *>(&k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
+                                                       : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>));
             const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
             if (he != hipSuccess) return he;
             raised = true;
@@ -1155,9 +1188,9 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     if (is_reset) {
         hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     } else if (P.n_steps > 1) {
-        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>), dim3(grid), dim3(BLOCK), lds, s, P);
+        hipLaunchKernelGGL((k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P.step_params, P.n_steps);
     } else {
-        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>), dim3(grid), dim3(BLOCK), lds, s, P);
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     }
     return hipGetLastError();
 }

@@ -48,7 +48,15 @@ def operators(n=1 << 20):
         env.compute_reward(ag, dg, info)
     torch.cuda.synchronize(); env.close()
 
-which = sys.argv[1:] or ['m4', 'm8', 'm16', 'box', 'f64', 'f64acc', 'jerk', 'holes', 'push', 'push2', 'views', 'ops']
+def rollout(E, M, tiles, T=50, launches=6):
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((tiles, tiles)), M, num_envs=E); env.reset(seed=0)
+    env.elapsed_steps.copy_(torch.randint(0, 50, (E,), device=dev, dtype=torch.int32))
+    acts = (torch.rand(T, E, 2 * M, device=dev) * 20 - 10)
+    roll = env.alloc_rollout(T)
+    for _ in range(launches): env.step_n(acts, roll)
+    torch.cuda.synchronize(); env.close()
+
+which = sys.argv[1:] or ['m4', 'm8', 'm16', 'box', 'f64', 'f64acc', 'jerk', 'holes', 'push', 'push2', 'views', 'ops', 'stepn']
 if 'm4' in which: planning(65536, 4, 6)
 if 'm8' in which: planning(65536, 8, 8)
 if 'm16' in which: planning(32768, 16, 10)
@@ -66,3 +74,4 @@ if 'push' in which: pushing(65536); pushing(4096)
 if 'push2' in which and hasattr(gpr.VecBenchmarkPushingEnv, 'supports_two_movers'): pushing(65536, num_movers=2); pushing(4096, num_movers=2)
 if 'views' in which: parallel(32768, 16, 10)
 if 'ops' in which: operators()
+if 'stepn' in which: rollout(65536, 4, 6); rollout(8192, 4, 6)

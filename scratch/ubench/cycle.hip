@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast -I../../gymnasium-planar-robotics_amd/csrc -I../../include cycle.hip -o cycle
 #include "gpr_device.h"
 #include <chrono>
+#include <type_traits>
 #include <cstdio>
 #include <vector>
 #include <algorithm>
@@ -41,11 +42,34 @@ template <int VAR> __global__ void __launch_bounds__(256) k(float *out, long lon
                 dp.x = __builtin_fmaf(dt_l, v.x, dp.x); dp.y = __builtin_fmaf(dt_l, v.y, dp.y);
             }
             if constexpr (VAR == 3) continue;
+            if constexpr (VAR == 8) {
+                // q, the wall reach and the four DPP subtracts as ONE block: the two reach instructions fill the two wait states a
+                // DPP read needs after the VALU write of its source, so no s_nop
+                float qx, qy, tt, e, dx1, dy1, dx2, dy2;
+                const float kw = cw.wx - cw.wy;
+                asm("v_add_f32 %0, %8, %10\n\tv_add_f32 %1, %9, %11\n\tv_add_f32_e64 %2, |%1|, %12\n\tv_max_f32_e64 %3, |%0|, %2\n\t"
+                    "v_sub_f32_dpp %4, %0, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_sub_f32_dpp %5, %1, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_sub_f32_dpp %6, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_sub_f32_dpp %7, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                    : "=&v"(qx), "=&v"(qy), "=&v"(tt), "=&v"(e), "=&v"(dx1), "=&v"(dy1), "=&v"(dx2), "=&v"(dy2)
+                    : "v"(q0.x), "v"(q0.y), "v"(dp.x), "v"(dp.y), "v"(kw));
+                eacc = __builtin_fmaxf(eacc, e);
+                macc = __builtin_fminf(macc, __builtin_fminf(__builtin_fmaf(dx1, dx1, dy1 * dy1), __builtin_fmaf(dx2, dx2, dy2 * dy2)));
+                continue;
+            }
             const R2<float> q{q0.x + dp.x, q0.y + dp.y};
             if constexpr (VAR != 2) eacc = __builtin_fmaxf(eacc, wall_reach_centred<float>(q.x, q.y, cw));
             if constexpr (VAR == 0 || VAR == 2 || VAR == 5) macc = __builtin_fminf(macc, pair_min_dist<float, 4>(q.x, q.y));
             if constexpr (VAR == 4) {
                 const float dx1 = rot<4, 1>(q.x) - q.x, dy1 = rot<4, 1>(q.y) - q.y, dx2 = rot<4, 2>(q.x) - q.x, dy2 = rot<4, 2>(q.y) - q.y;
+                macc = __builtin_fminf(macc, __builtin_fminf(__builtin_fmaf(dx1, dx1, dy1 * dy1), __builtin_fmaf(dx2, dx2, dy2 * dy2)));
+            }
+            if constexpr (VAR == 9) {  // partner coordinates through the LDS crossbar (ds_swizzle, quad-perm mode): no VALU DPP at all
+                auto swz = [](float v, auto pat) { return __uint_as_float((unsigned)__builtin_amdgcn_ds_swizzle((int)__float_as_uint(v), decltype(pat)::value)); };
+                const float x1 = swz(q.x, std::integral_constant<int, 0x8039>{}), y1 = swz(q.y, std::integral_constant<int, 0x8039>{});
+                const float x2 = swz(q.x, std::integral_constant<int, 0x804E>{}), y2 = swz(q.y, std::integral_constant<int, 0x804E>{});
+                const float dx1 = x1 - q.x, dy1 = y1 - q.y, dx2 = x2 - q.x, dy2 = y2 - q.y;
                 macc = __builtin_fminf(macc, __builtin_fminf(__builtin_fmaf(dx1, dx1, dy1 * dy1), __builtin_fmaf(dx2, dx2, dy2 * dy2)));
             }
             if constexpr (VAR == 7) {
@@ -90,6 +114,8 @@ int main() {
     printf("setup %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
     run<0>("quiet cycle as in k_step", out, clk);
     run<7>("same, one s_nop for the 4 DPP subs", out, clk);
+    run<8>("q + reach + 4 DPP subs in one block, no s_nop", out, clk);
+    run<9>("pair sweep via ds_swizzle (LDS crossbar)", out, clk);
     run<4>("pair sweep via compiler DPP movs", out, clk);
     run<1>("no pair sweep", out, clk);
     run<2>("no wall reach", out, clk);
