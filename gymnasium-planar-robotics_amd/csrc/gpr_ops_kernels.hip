@@ -138,12 +138,19 @@ template <typename ST, int LPE, int D> struct AgentGather {
         }
     }
 };
+// The rows of a wavefront's agents ((env, mover) in lane order, dead lanes skipped) are consecutive in agent_obs, each 4M+2 values
+// long (264 B for 16 movers): written by their own lanes they are 64 scattered 16-byte pieces per store instruction (measured: 38 %
+// more bytes written than the rows hold, partial sectors). So every wavefront assembles its rows in its own slice of LDS and then
+// streams the whole span out, consecutive lanes writing consecutive 16-byte (or 4-byte) pieces.
+constexpr int AV_BLOCK = 128;  // 2 wavefronts x 64 rows x (4 * 16 + 2) values x 4 B = 33 KB of LDS in the widest case (f64: 66 KB, raised)
 template <typename ST, int LPE>
-__global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_dim, ST *agent_obs, ST *agent_reward) {
-    const int M = P.M;
+__global__ void __launch_bounds__(AV_BLOCK) k_agent_views(const KParams P, int obs_dim, ST *agent_obs, ST *agent_reward) {
+    extern __shared__ __align__(16) unsigned char av_lds[];
+    const int M = P.M, W = 4 * M + 2;
     const ST *obs = static_cast<const ST *>(P.obs), *ag = static_cast<const ST *>(P.ag), *dg = static_cast<const ST *>(P.dg);
     const ST *reward = static_cast<const ST *>(P.reward);
-    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * AV_BLOCK + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
     const int mv = (int)(t & (LPE - 1));
     const int64_t env = t / LPE;
     const bool live = (env < P.E) & (mv < M);
@@ -152,9 +159,29 @@ __global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_
     const ST vx = obs[envc * obs_dim + 2 * mvc], vy = obs[envc * obs_dim + 2 * mvc + 1];
     const ST px = ag[envc * 2 * M + 2 * mvc], py = ag[envc * 2 * M + 2 * mvc + 1];
     const ST gx = dg[envc * 2 * M + 2 * mvc], gy = dg[envc * 2 * M + 2 * mvc + 1];
-    ST *row = agent_obs + (envc * M + mvc) * (int64_t)(4 * M + 2);
+    // this wavefront's slice of LDS: row r = (env index within the wavefront) * M + mover
+    ST *slice = reinterpret_cast<ST *>(av_lds) + (size_t)(threadIdx.x >> 6) * (64 / LPE) * M * W;
+    const int64_t env_w0 = (t - lane) / LPE;                      // first env of the wavefront
+    ST *row = slice + ((int)(env - env_w0) * M + mvc) * W;
     if (live) { row[0] = vx; row[1] = vy; row[2] = px; row[3] = py; row[4] = gx; row[5] = gy; }
     AgentGather<ST, LPE, 1>::run(px, py, vx, vy, live ? mv : LPE, M, row);  // dead lanes write nothing (mv = LPE fails mv < M)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wavefront's LDS writes have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // stream the span out
+    int64_t n_env = P.E - env_w0;
+    n_env = n_env < 0 ? 0 : (n_env > 64 / LPE ? 64 / LPE : n_env);
+    const int total = (int)n_env * M * W;                          // values in this wavefront's span
+    ST *dst = agent_obs + env_w0 * (int64_t)M * W;
+    constexpr int V = 16 / (int)sizeof(ST);                        // values per 16-byte piece
+    if ((((env_w0 * (int64_t)M * W) % V) == 0) & (sizeof(ST) == 4 || sizeof(ST) == 8)) {
+        typedef ST VecT __attribute__((ext_vector_type(V)));
+        const int nv = total / V;
+        for (int i = lane; i < nv; i += 64) reinterpret_cast<VecT *>(dst)[i] = reinterpret_cast<const VecT *>(slice)[i];
+        for (int i = nv * V + lane; i < total; i += 64) dst[i] = slice[i];
+    } else {
+        for (int i = lane; i < total; i += 64) dst[i] = slice[i];
+    }
     if (live) {
         // The env reward (PL:519-531) was computed from the state the step ended in. With same-step autoreset an env that ended
         // in this call already shows the new episode in obs / ag / dg: its terminal achieved / desired goal are in final_*.
@@ -171,9 +198,16 @@ __global__ void __launch_bounds__(BLOCK) k_agent_views(const KParams P, int obs_
     }
 }
 template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, void *agent_obs, void *agent_reward, hipStream_t s) {
-    const unsigned grid = grid_for(P.E * lpe);
+    const unsigned grid = (unsigned)((P.E * lpe + AV_BLOCK - 1) / AV_BLOCK);
+    const unsigned lds = (unsigned)((AV_BLOCK / 64) * (64 / lpe) * P.M * (4 * P.M + 2) * sizeof(ST));
+    hipError_t err = hipSuccess;
     auto a = [&](auto K) {
-        hipLaunchKernelGGL(K, dim3(grid), dim3(BLOCK), 0, s, P, obs_dim, static_cast<ST *>(agent_obs), static_cast<ST *>(agent_reward));
+        if (lds > 48u * 1024u) {
+            static bool raised = false;
+            if (!raised) { err = hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); raised = true; }
+        }
+        if (err == hipSuccess)
+            hipLaunchKernelGGL(K, dim3(grid), dim3(AV_BLOCK), lds, s, P, obs_dim, static_cast<ST *>(agent_obs), static_cast<ST *>(agent_reward));
     };
     switch (lpe) {
         case 1: a(k_agent_views<ST, 1>); break;
@@ -183,7 +217,7 @@ template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, 
         case 16: a(k_agent_views<ST, 16>); break;
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return err != hipSuccess ? err : hipGetLastError();
 }
 template hipError_t launch_agent_views<float>(const KParams &, int, int, void *, void *, hipStream_t);
 template hipError_t launch_agent_views<double>(const KParams &, int, int, void *, void *, hipStream_t);
