@@ -192,6 +192,33 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// gpr-rng-v1 in double: radius and (cos, sin) tables over the 16-bit halves of a draw (gpr_device.h), filled with this host's libm
+// exactly as oracle/gpr_oracle.c:gpro_rng_normal_pair computes them. One set per device, kept for the life of the process.
+hipError_t ensure_normal_tables() {
+    static std::vector<int> ready;
+    int dev = 0;
+    hipError_t he = hipGetDevice(&dev);
+    if (he != hipSuccess) return he;
+    for (int d : ready) if (d == dev) return hipSuccess;
+    std::vector<double> h((size_t)3 * 65536);
+    for (uint32_t k = 0; k < 65536u; ++k) {
+        const double u1 = (double)(k + 1u) * (1.0 / 65536.0), u2 = (double)k * (1.0 / 65536.0);
+        h[k] = std::sqrt(-2.0 * std::log(u1));
+        const double ang = 6.283185307179586476925286766559 * u2;
+        h[(size_t)65536 + 2 * k] = std::cos(ang);
+        h[(size_t)65536 + 2 * k + 1] = std::sin(ang);
+    }
+    double *d = nullptr;
+    he = hipMalloc(reinterpret_cast<void **>(&d), h.size() * sizeof(double));
+    if (he != hipSuccess) return he;
+    he = hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = set_normal_table_env<float, double>(d);
+    if (he == hipSuccess) he = set_normal_table_env<double, double>(d);
+    if (he == hipSuccess) he = set_normal_table_push(d);
+    if (he == hipSuccess) ready.push_back(dev);
+    return he;
+}
+
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
 KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
@@ -309,6 +336,10 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     }
     if (n_tiles == 0) return fail(nullptr, GPR_E_INVALID, "layout_tiles has no tile");
 
+    {
+        const hipError_t he = ensure_normal_tables();
+        if (he != hipSuccess) return fail_hip(nullptr, he, "gpr_create: normal-draw tables");
+    }
     gpr_env *e = new gpr_env();
     e->cfg = c;
     e->layout.assign(c.layout_tiles, c.layout_tiles + (size_t)c.num_tiles_x * c.num_tiles_y);

@@ -180,13 +180,18 @@ template <> __device__ __forceinline__ R2<float> rng_normal_pair<float>(uint32_t
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * (__builtin_amdgcn_logf(a) - 16.0f));
     return R2<float>{rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
 }
+// Double precision: log / sin / cos in double are several hundred instructions per draw (the parity kernels spent half their
+// vector instructions in them), and both arguments take only 65 536 values each. So the radius sqrt(-2 ln((k + 1) / 65536)) and
+// the pair (cos, sin)(2 pi k / 65536) come from two tables in device memory (1.5 MB, L2-resident), filled once per device by
+// gpr_create with the host's libm -- the very values the oracle's libm computes, so the noise is bit-identical to the oracle's.
+// One translation unit = one instance of this pointer (set through set_normal_table_* of that unit).
+static __device__ const double *g_normal_tab = nullptr;  // [65536] radius, then [65536][2] (cos, sin)
 template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32_t key, uint32_t q) {
     const uint32_t r = rng_draw(key, q);
-    const double u1 = (double)((r >> 16) + 1u) * (1.0 / 65536.0);
-    const double u2 = (double)(r & 0xFFFFu) * (1.0 / 65536.0);
-    const double rad = sqrt(-2.0 * log(u1));
-    const double ang = 6.283185307179586476925286766559 * u2;
-    return R2<double>{rad * cos(ang), rad * sin(ang)};
+    const double *tab = g_normal_tab;
+    const double rad = tab[r >> 16];
+    const double2 cs = reinterpret_cast<const double2 *>(tab + 65536)[r & 0xFFFFu];
+    return R2<double>{rad * cs.x, rad * cs.y};
 }
 
 // a noisy 2-vector reading: value + sigma * N(0,1) per component (BE:828,841), from normal pair q of the lane's stream

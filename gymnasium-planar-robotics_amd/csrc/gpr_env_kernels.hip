@@ -1235,6 +1235,11 @@ template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, 
 #ifndef GPR_ENV_TYPES
 #error "define GPR_ENV_TYPES as ST,RT (one translation unit per precision)"
 #endif
+// this translation unit's instance of the normal-draw tables (gpr_device.h)
+template <typename ST, typename RT> hipError_t set_normal_table_env(const double *tab) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_normal_tab), &tab, sizeof(tab));
+}
+template hipError_t set_normal_table_env<GPR_ENV_TYPES>(const double *);
 template hipError_t launch_env_kernel<GPR_ENV_TYPES>(bool, int, const KParams &, hipStream_t);
 
 }  // namespace gpr

@@ -12,6 +12,10 @@ template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, 
 // sums the per-wavefront episode counters [rows][6] into totals[6] (uint64, added) and clears the rows
 hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, hipStream_t s);
 
+// the double-precision normal-draw tables (gpr_device.h: g_normal_tab), one pointer instance per translation unit that draws in double
+template <typename ST, typename RT> hipError_t set_normal_table_env(const double *tab);
+hipError_t set_normal_table_push(const double *tab);
+
 // BenchmarkPushingEnv kernels (gpr_push_kernels.hip)
 template <typename ST, typename RT> hipError_t launch_push(bool is_reset, const KParams &P, const PushCst<RT> &Q, const PushPtrs &X, hipStream_t s);
 

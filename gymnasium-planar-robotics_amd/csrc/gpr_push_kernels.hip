@@ -545,6 +545,7 @@ template <typename ST, typename RT> hipError_t launch_push(bool is_reset, const 
         return noise ? launch_push2<ST, RT, false, true, false>(is_reset, P, Q, X, s) : launch_push2<ST, RT, false, false, false>(is_reset, P, Q, X, s);
     }
 }
+hipError_t set_normal_table_push(const double *tab) { return hipMemcpyToSymbol(HIP_SYMBOL(g_normal_tab), &tab, sizeof(tab)); }
 template hipError_t launch_push<float, float>(bool, const KParams &, const PushCst<float> &, const PushPtrs &, hipStream_t);
 template hipError_t launch_push<float, double>(bool, const KParams &, const PushCst<double> &, const PushPtrs &, hipStream_t);
 template hipError_t launch_push<double, double>(bool, const KParams &, const PushCst<double> &, const PushPtrs &, hipStream_t);
