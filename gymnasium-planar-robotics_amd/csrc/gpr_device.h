@@ -386,6 +386,20 @@ __device__ __forceinline__ bool pos_valid_circle(const Tables<RT> &T, const KPar
                                                  bool *uncertain = nullptr) {
     const int Tx = P.Tx, Ty = P.Ty;
     if constexpr (Math<RT>::literal) {
+        if constexpr (FULL) {
+            // grid without holes: BE:459-788 is "the circle's bounding box lies strictly inside the grid" (see the throughput
+            // branch); the table edges are the reference's to within rounding, so a margin beyond 1e-9 (+ band) decides, for
+            // this position and for every read displaced by up to `band` -- only a wavefront with a lane closer than that to the
+            // outer limit walks the tables
+            const Cst<RT> &C = cst<RT>(P);
+            const RT mx = cs.wx - absr(x - (RT)0.5 * (C.gx0 + C.gx1)), my = cs.wy - absr(y - (RT)0.5 * (C.gy0 + C.gy1));
+            const RT m = mx < my ? mx : my, room = band + (RT)1e-9;
+            const bool in = m > room, out = m < -room;
+            if (__ballot(!(in | out)) == 0ull) {
+                if constexpr (UNC) *uncertain = false;
+                return in;
+            }
+        }
         // parity mode: every compare against the tile edges exactly as NumPy formed them
         const RT c = cs.c;
         int ix = clampi(Math<RT>::floor_int(x * cst<RT>(P).inv_wx), 0, Tx - 1);
@@ -745,6 +759,31 @@ template <typename RT, int LPE> __device__ __forceinline__ RT pair_min_d2(RT x, 
 // compare a pair_min_dist result against a distance limit: <= (collision, BE:409) or < (goal spacing, PL:409)
 template <typename RT> __device__ __forceinline__ bool dist_le(RT m, RT lim) { return Math<RT>::literal ? (m <= lim) : (m <= lim * lim); }
 template <typename RT> __device__ __forceinline__ bool dist_lt(RT m, RT lim) { return Math<RT>::literal ? (m < lim) : (m < lim * lim); }
+// Parity mode, "sqrt(d2) <= lim" (STRICT: "< lim") as the reference forms it, without the square root wherever it cannot
+// matter: a correctly rounded square root is monotone and exact to half an ulp, so d2 outside lim^2 (1 -+ 1e-12) decides the
+// compare; only a wavefront with a lane inside that sliver takes the root (a double sqrt is ~19 instructions, a division ~12:
+// scratch/ubench/f64.hip). Wave-cooperative (it votes): call convergently.
+template <typename RT, bool STRICT> __device__ __forceinline__ bool sqrt_within(RT d2, RT lim) {
+    if constexpr (!Math<RT>::literal) {
+        return STRICT ? d2 < lim * lim : d2 <= lim * lim;
+    } else {
+        const RT l2 = lim * lim;
+        const bool in = d2 < l2 * (RT)(1.0 - 1e-12), out = d2 > l2 * (RT)(1.0 + 1e-12);
+        if (__ballot(!(in | out)) == 0ull) return in;
+        const RT d = Math<RT>::sqrt_(d2);
+        return STRICT ? d < lim : d <= lim;
+    }
+}
+// is any partner of this lane's env group closer than lim (BE:409 inclusive; STRICT: PL:409)? pair_min_dist + dist_le / dist_lt
+// with the parity-mode roots taken only in the sliver above (the minimum of the roots is the root of the minimum).
+template <typename RT, int LPE, bool STRICT> __device__ __forceinline__ bool pair_closer(RT x, RT y, RT lim) {
+    if constexpr (!Math<RT>::literal) {
+        const RT m = pair_min_dist<RT, LPE>(x, y);
+        return STRICT ? dist_lt<RT>(m, lim) : dist_le<RT>(m, lim);
+    } else {
+        return sqrt_within<RT, STRICT>(pair_min_d2<RT, LPE>(x, y), lim);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ensure_max_dyn_val (PL:610-645) for one mover: returns the derivative to apply; `next` receives the next value

@@ -41,7 +41,7 @@ __device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint3
     // the reward is a function of the returned (stored) achieved / desired goal
     RT dx = stored<ST, RT>(o.ag.x) - g.x, dy = stored<ST, RT>(o.ag.y) - g.y;
     RT d2 = dx * dx + dy * dy;
-    bool reached = live & (Math<RT>::literal ? (Math<RT>::sqrt_(d2) <= C.thr) : (d2 <= C.thr * C.thr));  // PL:524, inclusive
+    bool reached = live & sqrt_within<RT, false>(d2, C.thr);  // PL:524, inclusive
     int n_reached = __popc(group_bits<LPE>(reached));
     bool coll = mc | wc;
     RT r = -C.reward_success * (RT)coll;                      // PL:529
@@ -112,8 +112,8 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             bool w, hit;
             if constexpr (SHAPE == 0) {
                 w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                    // PL:379 / PL:403-404
-                const RT md = pair_min_dist<RT, LPE>(cn.x, cn.y);
-                hit = live & (pass == 0 ? dist_le<RT>(md, C.max_csum_safe) : dist_lt<RT>(md, C.min_goal_dist));  // PL:381-383 / PL:407-413
+                hit = live & (pass == 0 ? pair_closer<RT, LPE, false>(cn.x, cn.y, C.max_csum_safe)
+                                        : pair_closer<RT, LPE, true>(cn.x, cn.y, C.min_goal_dist));  // PL:381-383 / PL:407-413
             } else {
                 const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
                 if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
@@ -159,7 +159,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             R2<RT> pw = noisy<RT, NOISE>(p, C.sig_p, kn, 0u);
             wc = group_any<LPE>(live & !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_safe));
             R2<RT> pp = noisy<RT, NOISE>(p, C.sig_p, kn, R);
-            mc = group_any<LPE>(live & dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+            mc = group_any<LPE>(live & pair_closer<RT, LPE, false>(pp.x, pp.y, C.max_csum_step));
         }
     } else {
         bool lazy_done = false;
@@ -739,6 +739,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                                 const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
                                 const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
                                 ++vg_rows;
+                                GPR_WT(++wt_rows;)
                                 VgVec w; w.x = C.sig_v * n.x; w.y = C.sig_v * n.y;
                                 vg_tab[vg_wave][vg_rows][__lane_id()] = w;
                                 if ((int)__lane_id() == L) vg_ptr = &vg_tab[vg_wave][vg_rows][0];
@@ -841,19 +842,29 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                 wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step));
             }
             hraw = 0ull;
-            if (eager | ((__ballot(pair_min_d2<RT, LPE>(pc.x, pc.y) <= pair_near2) & live_m) != 0ull)) {  // else: no pair can touch
-                const RT md = pair_min_dist<RT, LPE>(pc.x, pc.y);
-                hraw = __ballot(md <= pair_thr);  // BE:409, inclusive
-                if (eager | ((__ballot(absr(md - pair_thr) <= pair_band) & live_m) != 0ull)) {
+            const RT md2 = pair_min_d2<RT, LPE>(pc.x, pc.y);
+            if (eager | ((__ballot(md2 <= pair_near2) & live_m) != 0ull)) {  // else: no pair can touch
+                bool near_thr;
+                if constexpr (Math<RT>::literal) {
+                    hraw = __ballot(sqrt_within<RT, false>(md2, C.max_csum_step));  // BE:409, inclusive
+                    // |dist - limit| <= band, asked of d2 (a superset: more draws at most, never another verdict)
+                    const RT lo = C.max_csum_step - pair_band, hi = C.max_csum_step + pair_band;
+                    near_thr = ((lo <= (RT)0) | (md2 >= lo * lo * (RT)(1.0 - 1e-12))) & (md2 <= hi * hi * (RT)(1.0 + 1e-12));
+                } else {
+                    const RT md = pair_min_dist<RT, LPE>(pc.x, pc.y);
+                    hraw = __ballot(md <= pair_thr);
+                    near_thr = absr(md - pair_thr) <= pair_band;
+                }
+                if (eager | ((__ballot(near_thr) & live_m) != 0ull)) {
                     const R2<RT> pp = noisy<RT, true>(pc, C.sig_p, key, S * (uint32_t)cyc + 1u + R);
-                    hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pp.x, pp.y), C.max_csum_step));
+                    hraw = __ballot(pair_closer<RT, LPE, false>(pp.x, pp.y, C.max_csum_step));
                 }
             }
         } else {
             wraw = __ballot(!pos_valid_circle<RT, FULL>(T, P, pc.x, pc.y, cw_step));
             hraw = 0ull;
             if ((__ballot(pair_min_d2<RT, LPE>(pc.x, pc.y) <= pair_near2) & live_m) != 0ull)
-                hraw = __ballot(dist_le<RT>(pair_min_dist<RT, LPE>(pc.x, pc.y), C.max_csum_step));
+                hraw = __ballot(pair_closer<RT, LPE, false>(pc.x, pc.y, C.max_csum_step));
         }
     };
     auto settle = [&](unsigned long long wraw, unsigned long long hraw) {
@@ -867,6 +878,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         return nf;
     };
     int cyc = 0;
+    GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
     if constexpr (Math<RT>::literal && FULL && SHAPE == 0) {
         // PARITY MODE ON A GRID WITHOUT HOLES: the reference's arithmetic, but its checks only where they can matter. The state
         // advances in double exactly as above (v += dt a; p += dt v, the same operations in the same order). Whether a cycle
@@ -902,6 +914,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         };
         auto literal_cycle = [&](int c, R2<RT> pc, R2<RT> vc) {  // the literal checks of cycle c on its saved state
             unsigned long long wraw, hraw;
+            GPR_WT(++wt_exact;)
             checks(c, pc, wraw, hraw);
             const unsigned long long nf = settle(wraw, hraw);
             if (nf != 0ull) {
@@ -913,6 +926,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                 const RT t0 = v.x + dta_d.x, t1 = v.y + dta_d.y, n2 = t0 * t0 + t1 * t1;
                 if (JERK | (__ballot(!(n2 < r1)) != 0ull)) {
                     // some lane may clamp within this block: its cycles one by one (advance() decides about readings and clamp)
+                    GPR_WT(wt_clamp += KB;)
                     for (int j = 0; j < KB; ++j, ++cyc) {
                         advance(cyc);
                         float e, m;
@@ -924,8 +938,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                 next_c = cyc + 1 + (__ballot(!(n2 < r2)) != 0ull ? KB - 1 : __ballot(!(n2 < r3)) != 0ull ? 3 * KB - 1 : P.num_cycles - 1);
             }
             // a quiet block: qacc = a in every cycle (PL:636-637)
-            const R2<RT> vb = v;
-            R2<RT> ps[KB];
+            const R2<RT> vb = v, pb = p;
             float es[KB], ms[KB], eacc = -INFf, macc = INFf;
             const bool moving = !lane_of(frozen_m);
 #pragma unroll
@@ -934,18 +947,23 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                     v.x = v.x + dta_d.x; v.y = v.y + dta_d.y;
                     p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
                 }
-                ps[j] = p;
                 reaches(p, es[j], ms[j]);
                 eacc = __builtin_fmaxf(eacc, es[j]); macc = __builtin_fminf(macc, ms[j]);
             }
             if (moving) acc = a;
             if ((__ballot(!(eacc < w0f)) | __ballot(macc <= p0f)) != 0ull) {
-#pragma unroll
+                // the state a flagged cycle ended with: the same additions again from the block's start (registers for the
+                // four saved positions would cost the kernel a wavefront per SIMD)
+                R2<RT> vj = vb, pj = pb;
                 for (int j = 0; j < KB; ++j) {
-                    if ((__ballot(!(es[j] < w0f)) | __ballot(ms[j] <= p0f)) == 0ull) continue;
-                    R2<RT> vj = vb;  // the velocity cycle j ended with: the same j + 1 additions again
-                    for (int i = 0; i <= j; ++i) { vj.x = vj.x + dta_d.x; vj.y = vj.y + dta_d.y; }
-                    literal_cycle(cyc + j, ps[j], vj);
+                    if (moving) {
+                        vj.x = vj.x + dta_d.x; vj.y = vj.y + dta_d.y;
+                        pj.x = pj.x + C.dt * vj.x; pj.y = pj.y + C.dt * vj.y;
+                    }
+                    const float ej = j == 0 ? es[0] : j == 1 ? es[1] : j == 2 ? es[2] : es[3];
+                    const float mj = j == 0 ? ms[0] : j == 1 ? ms[1] : j == 2 ? ms[2] : ms[3];
+                    if ((__ballot(!(ej < w0f)) | __ballot(mj <= p0f)) == 0ull) continue;
+                    literal_cycle(cyc + j, pj, vj);
                 }
             }
             cyc += KB;
@@ -957,6 +975,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         checks(cyc, p, wraw, hraw);
         (void)settle(wraw, hraw);
     }
+    GPR_WT(wt_loop1 = __builtin_amdgcn_s_memtime();)
     }
     wc_m = group_or<LPE>(wc_m);
     mc_m = group_or<LPE>(mc_m);
@@ -1107,7 +1126,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
 }
 
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK) k_step(const KParams P) {
+__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step(const KParams P) {
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:
