@@ -939,7 +939,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
             }
             // a quiet block: qacc = a in every cycle (PL:636-637)
             const R2<RT> vb = v, pb = p;
-            float es[KB], ms[KB], eacc = -INFf, macc = INFf;
+            float eacc = -INFf, macc = INFf;
             const bool moving = !lane_of(frozen_m);
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
@@ -947,22 +947,24 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                     v.x = v.x + dta_d.x; v.y = v.y + dta_d.y;
                     p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
                 }
-                reaches(p, es[j], ms[j]);
-                eacc = __builtin_fmaxf(eacc, es[j]); macc = __builtin_fminf(macc, ms[j]);
+                float e, m;
+                reaches(p, e, m);
+                eacc = __builtin_fmaxf(eacc, e); macc = __builtin_fminf(macc, m);
             }
             if (moving) acc = a;
             if ((__ballot(!(eacc < w0f)) | __ballot(macc <= p0f)) != 0ull) {
-                // the state a flagged cycle ended with: the same additions again from the block's start (registers for the
-                // four saved positions would cost the kernel a wavefront per SIMD)
+                // a flagged block (rare): its cycles again from the block's start, the same additions in the same order, each
+                // with its own decision (keeping the four positions and their distances in registers instead would cost the
+                // kernel its fourth wavefront per SIMD)
                 R2<RT> vj = vb, pj = pb;
                 for (int j = 0; j < KB; ++j) {
                     if (moving) {
                         vj.x = vj.x + dta_d.x; vj.y = vj.y + dta_d.y;
                         pj.x = pj.x + C.dt * vj.x; pj.y = pj.y + C.dt * vj.y;
                     }
-                    const float ej = j == 0 ? es[0] : j == 1 ? es[1] : j == 2 ? es[2] : es[3];
-                    const float mj = j == 0 ? ms[0] : j == 1 ? ms[1] : j == 2 ? ms[2] : ms[3];
-                    if ((__ballot(!(ej < w0f)) | __ballot(mj <= p0f)) == 0ull) continue;
+                    float e, m;
+                    reaches(pj, e, m);
+                    if ((__ballot(!(e < w0f)) | __ballot(m <= p0f)) == 0ull) continue;
                     literal_cycle(cyc + j, pj, vj);
                 }
             }
@@ -1126,7 +1128,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
 }
 
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step(const KParams P) {
+__global__ void __launch_bounds__(BLOCK, (Math<RT>::literal && SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step(const KParams P) {
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:
