@@ -162,6 +162,159 @@ __device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT>
     o.x += dt * o.vx; o.y += dt * o.vy; o.th += dt * o.w;
 }
 
+// THROUGHPUT FORM of push_cycle (float arithmetic only): the same model, the same order of the sequential impulses, written for
+// the fewest vector instructions -- one lane per env and one wavefront per SIMD at 65 536 envs means the kernel lasts as long as
+// the instruction chain of a wavefront in which some env is in contact, ~1 000 instructions per cycle in the literal form above:
+//   * the geometry of a pair lives in the MOVER's frame: one relative rotation, two of the four SAT axes are coordinate axes,
+//     the object's vertices are four sums and the mover's are constants;
+//   * the eight "vertex inside the other box" tests only set bits of a mask; the (at most PUSH_SLOTS) contact points are then
+//     rebuilt from their bit index -- no register arrays written through selects;
+//   * the relative velocity at a contact point along n / t is n.(vo - vm) + wo (ro x n) - wm (rm x n): the lever arms
+//     themselves are never stored, the products with the inverse masses / inertias are formed once per cycle.
+// Equal to push_cycle up to float rounding (tests/test_gpu_pushing.py holds the float build to the oracle through it).
+template <int NM>
+__device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float dt, Body<float> (&mv)[NM], Body<float> &o, const R2<float> (&u)[NM]) {
+    // 1. external forces
+    const float w_gain = dt * Q.Kr * Q.inv_Im, w_den = __builtin_amdgcn_rcpf(1.f + dt * Q.Dr * Q.inv_Im);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        Body<float> &m = mv[i];
+        m.vx = __builtin_fmaf(dt, u[i].x, m.vx);
+        m.vy = __builtin_fmaf(dt, u[i].y, m.vy);
+        m.w = __builtin_fmaf(-w_gain, m.th, m.w) * w_den;
+    }
+    {
+        const float vx = o.vx * Q.damp_lin, vy = o.vy * Q.damp_lin, w = o.w * __builtin_amdgcn_rcpf(Q.damp_rot_den);
+        const float sp2 = __builtin_fmaf(vx, vx, vy * vy);
+        const float k = sp2 > Q.fric_dv * Q.fric_dv ? __builtin_fmaf(-Q.fric_dv, __builtin_amdgcn_rsqf(sp2), 1.f) : 0.f;  // (sp - dv) / sp
+        o.vx = vx * k; o.vy = vy * k;
+        const float aw = __builtin_fabsf(w);
+        o.w = aw <= Q.fric_dw ? 0.f : __builtin_copysignf(aw - Q.fric_dw, w);
+    }
+    // 2. contact geometry per pair (mover i, object), in mover i's frame
+    struct Pair {
+        int np;
+        float nx, ny;
+        float rmn[PUSH_SLOTS], ron[PUSH_SLOTS], rmt[PUSH_SLOTS], rot_[PUSH_SLOTS];  // lever arms x n, x t
+        float wmn[PUSH_SLOTS], won[PUSH_SLOTS], wmt[PUSH_SLOTS], wot[PUSH_SLOTS];   // ... times the inverse inertias
+        float inv_kn[PUSH_SLOTS], inv_kt[PUSH_SLOTS], bias[PUSH_SLOTS], jn[PUSH_SLOTS], jt[PUSH_SLOTS];
+    };
+    Pair pr[NM];
+    bool any_contact = false;
+    float so = 0.f, co = 1.f;
+    bool have_o = false;
+    const float imm = Q.inv_mm + Q.inv_mo, inv_tc = __builtin_amdgcn_rcpf(Q.tc);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const Body<float> &m = mv[i];
+        Pair &q = pr[i];
+        q.np = 0; q.nx = 0.f; q.ny = 0.f;
+        const float dx = o.x - m.x, dy = o.y - m.y;
+        const bool in_range = !(__builtin_fmaf(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
+        if (__ballot(in_range) == 0ull) continue;
+        if (!have_o) { Math<float>::sincos_(o.th, so, co); have_o = true; }
+        float sm, cm;
+        Math<float>::sincos_(m.th, sm, cm);
+        const float c = __builtin_fmaf(co, cm, so * sm), s = __builtin_fmaf(so, cm, -(co * sm));  // the object's axes in the mover's frame: (c, s), (-s, c)
+        const float lx = __builtin_fmaf(dx, cm, dy * sm), ly = __builtin_fmaf(dy, cm, -(dx * sm)); // the object's centre in the mover's frame
+        const float ac = __builtin_fabsf(c), as = __builtin_fabsf(s);
+        // separating axes in the order of push_cycle: mover x, mover y, object x, object y; the first smallest overlap wins
+        const float ro01 = Q.h * (ac + as);
+        const float d2 = __builtin_fmaf(lx, c, ly * s), d3 = __builtin_fmaf(ly, c, -(lx * s));
+        const float ov0 = (Q.ax + ro01) - __builtin_fabsf(lx), ov1 = (Q.ay + ro01) - __builtin_fabsf(ly);
+        const float ov2 = (__builtin_fmaf(Q.ax, ac, Q.ay * as) + Q.h) - __builtin_fabsf(d2);
+        const float ov3 = (__builtin_fmaf(Q.ax, as, Q.ay * ac) + Q.h) - __builtin_fabsf(d3);
+        const bool touching = in_range & !(__builtin_fminf(__builtin_fminf(ov0, ov1), __builtin_fminf(ov2, ov3)) < 0.f);
+        if (__ballot(touching) == 0ull) continue;
+        any_contact = true;
+        float best = ov0, nlx = __builtin_copysignf(1.f, lx), nly = 0.f;  // the normal in the mover's frame, towards the object
+        { const bool t = ov1 < best; best = t ? ov1 : best; nlx = t ? 0.f : nlx; nly = t ? __builtin_copysignf(1.f, ly) : nly; }
+        { const bool t = ov2 < best; best = t ? ov2 : best; nlx = t ? __builtin_copysignf(c, c * d2) : nlx; nly = t ? __builtin_copysignf(s, s * d2) : nly; }
+        { const bool t = ov3 < best; best = t ? ov3 : best; nlx = t ? __builtin_copysignf(s, -(s * d3)) : nlx; nly = t ? __builtin_copysignf(c, c * d3) : nly; }
+        const float nx = __builtin_fmaf(nlx, cm, -(nly * sm)), ny = __builtin_fmaf(nlx, sm, nly * cm);
+        const float rm_n = __builtin_fmaf(Q.ax, __builtin_fabsf(nlx), Q.ay * __builtin_fabsf(nly));
+        const float ro_n = Q.h * (__builtin_fabsf(__builtin_fmaf(nlx, c, nly * s)) + __builtin_fabsf(__builtin_fmaf(nly, c, -(nlx * s))));
+        // candidates: bit k = object vertex k inside the mover, bit 4 + k = mover vertex k inside the object (vertex order of push_cycle)
+        const float hc = Q.h * c, hs = Q.h * s, e1 = hc - hs, e2 = hc + hs;
+        auto in_m = [&](float vx, float vy) { return (__builtin_fabsf(vx) <= Q.ax) & (__builtin_fabsf(vy) <= Q.ay); };
+        const float qxm = -Q.ax - lx, qxp = Q.ax - lx, qym = -Q.ay - ly, qyp = Q.ay - ly;  // mover vertices relative to the object's centre
+        const float qyms = qym * s, qyps = qyp * s, qxms = qxm * s, qxps = qxp * s;
+        auto in_o = [&](float qx, float qy, float qys, float qxs) {
+            return (__builtin_fabsf(__builtin_fmaf(qx, c, qys)) <= Q.h) & (__builtin_fabsf(__builtin_fmaf(qy, c, -qxs)) <= Q.h);
+        };
+        unsigned mask = (in_m(lx - e1, ly - e2) ? 1u : 0u) | (in_m(lx - e2, ly + e1) ? 2u : 0u) | (in_m(lx + e1, ly + e2) ? 4u : 0u) |
+                        (in_m(lx + e2, ly - e1) ? 8u : 0u) | (in_o(qxm, qym, qyms, qxms) ? 16u : 0u) | (in_o(qxm, qyp, qyps, qxms) ? 32u : 0u) |
+                        (in_o(qxp, qyp, qyps, qxps) ? 64u : 0u) | (in_o(qxp, qym, qyms, qxps) ? 128u : 0u);
+        mask = touching ? mask : 0u;
+        const bool lone = touching & (mask == 0u);  // boxes overlap but no vertex is inside the other: one point between the centres
+        const int np_raw = __popc(mask);
+        const int np = lone ? 1 : (np_raw < PUSH_SLOTS ? np_raw : PUSH_SLOTS);
+        q.np = np; q.nx = nx; q.ny = ny;
+#pragma unroll
+        for (int k = 0; k < PUSH_SLOTS; ++k) {
+            if (__ballot(k < np) == 0ull) break;
+            const int idx = mask != 0u ? __builtin_ctz(mask) : 0;
+            mask &= mask - 1u;
+            const bool of_mover = idx >= 4;
+            const float sxf = (idx & 2) ? 1.f : -1.f, syf = ((idx + 1) & 2) ? 1.f : -1.f;
+            // the point in the mover's frame and its depth along n
+            float px = of_mover ? sxf * Q.ax : __builtin_fmaf(-syf, hs, __builtin_fmaf(sxf, hc, lx));
+            float py = of_mover ? syf * Q.ay : __builtin_fmaf(syf, hc, __builtin_fmaf(sxf, hs, ly));
+            const float pn = of_mover ? __builtin_fmaf(px - lx, nlx, (py - ly) * nly) : -__builtin_fmaf(px, nlx, py * nly);
+            float dep = (of_mover ? ro_n : rm_n) + pn;
+            float rmx = __builtin_fmaf(px, cm, -(py * sm)), rmy = __builtin_fmaf(px, sm, py * cm);
+            if (k == 0) { rmx = lone ? 0.5f * dx : rmx; rmy = lone ? 0.5f * dy : rmy; dep = lone ? best : dep; }
+            const float rox = rmx - dx, roy = rmy - dy;
+            const float rmn = __builtin_fmaf(rmx, ny, -(rmy * nx)), ron = __builtin_fmaf(rox, ny, -(roy * nx));
+            const float rmt = __builtin_fmaf(rmx, nx, rmy * ny), rot = __builtin_fmaf(rox, nx, roy * ny);  // r x t with t = (-ny, nx)
+            q.rmn[k] = rmn; q.ron[k] = ron; q.rmt[k] = rmt; q.rot_[k] = rot;
+            q.wmn[k] = rmn * Q.inv_Im; q.won[k] = ron * Q.inv_Io; q.wmt[k] = rmt * Q.inv_Im; q.wot[k] = rot * Q.inv_Io;
+            q.inv_kn[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmn, q.wmn[k], __builtin_fmaf(ron, q.won[k], imm)));
+            q.inv_kt[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmt, q.wmt[k], __builtin_fmaf(rot, q.wot[k], imm)));
+            q.bias[k] = __builtin_fmaxf(dep, 0.f) * inv_tc;
+            q.jn[k] = 0.f; q.jt[k] = 0.f;
+        }
+    }
+    // 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points
+    if (any_contact) {  // (wave-uniform)
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                Body<float> &m = mv[i];
+                Pair &q = pr[i];
+                const float nx = q.nx, ny = q.ny;
+                const float nmx = nx * Q.inv_mm, nmy = ny * Q.inv_mm, nox = nx * Q.inv_mo, noy = ny * Q.inv_mo;
+#pragma unroll
+                for (int k = 0; k < PUSH_SLOTS; ++k) {
+                    if (__ballot(k < q.np) == 0ull) break;
+                    if (k < q.np) {
+                        float dvx = o.vx - m.vx, dvy = o.vy - m.vy;
+                        const float vn = __builtin_fmaf(dvx, nx, __builtin_fmaf(dvy, ny, __builtin_fmaf(o.w, q.ron[k], -(m.w * q.rmn[k]))));
+                        const float jn_new = __builtin_fmaxf(__builtin_fmaf(q.bias[k] - vn, q.inv_kn[k], q.jn[k]), 0.f);
+                        const float dj = jn_new - q.jn[k];
+                        q.jn[k] = jn_new;
+                        m.vx = __builtin_fmaf(-dj, nmx, m.vx); m.vy = __builtin_fmaf(-dj, nmy, m.vy); m.w = __builtin_fmaf(-dj, q.wmn[k], m.w);
+                        o.vx = __builtin_fmaf(dj, nox, o.vx); o.vy = __builtin_fmaf(dj, noy, o.vy); o.w = __builtin_fmaf(dj, q.won[k], o.w);
+                        dvx = o.vx - m.vx; dvy = o.vy - m.vy;
+                        const float vt = __builtin_fmaf(dvy, nx, __builtin_fmaf(-dvx, ny, __builtin_fmaf(o.w, q.rot_[k], -(m.w * q.rmt[k]))));
+                        const float lim = Q.mu * jn_new;
+                        const float jt_new = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-vt, q.inv_kt[k], q.jt[k]), -lim), lim);
+                        const float djt = jt_new - q.jt[k];
+                        q.jt[k] = jt_new;
+                        // t = (-ny, nx)
+                        m.vx = __builtin_fmaf(djt, nmy, m.vx); m.vy = __builtin_fmaf(-djt, nmx, m.vy); m.w = __builtin_fmaf(-djt, q.wmt[k], m.w);
+                        o.vx = __builtin_fmaf(-djt, noy, o.vx); o.vy = __builtin_fmaf(djt, nox, o.vy); o.w = __builtin_fmaf(djt, q.wot[k], o.w);
+                    }
+                }
+            }
+        }
+    }
+    // 4. positions with the new velocities
+#pragma unroll
+    for (int i = 0; i < NM; ++i) { Body<float> &m = mv[i]; m.x = __builtin_fmaf(dt, m.vx, m.x); m.y = __builtin_fmaf(dt, m.vy, m.y); m.th = __builtin_fmaf(dt, m.w, m.th); }
+    o.x = __builtin_fmaf(dt, o.vx, o.x); o.y = __builtin_fmaf(dt, o.vy, o.y); o.th = __builtin_fmaf(dt, o.w, o.th);
+}
+
 template <typename RT, int NM> struct PushObs {
     R2<RT> mpos[NM], mvel[NM], ag;
     RT reward;
@@ -424,7 +577,9 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
             Body<RT> m2[NM], o2 = o;
 #pragma unroll
             for (int i = 0; i < NM; ++i) m2[i] = m[i];
-            push_cycle<RT, NM>(Q, C.dt, m2, o2, qacc);  // mj_step (BE:1882): engine model gpr-push-v2
+            // mj_step (BE:1882): engine model gpr-push-v2
+            if constexpr (Math<RT>::literal) push_cycle<RT, NM>(Q, C.dt, m2, o2, qacc);
+            else push_cycle_fast<NM>(Q, C.dt, m2, o2, qacc);
             if (!frozen) {
                 o = o2;
 #pragma unroll
