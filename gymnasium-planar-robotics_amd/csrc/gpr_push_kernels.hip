@@ -574,16 +574,13 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                     qacc[i] = clamp_dyn<RT>(vn, C.v_max, a[i], C.dt, C.inv_dt, vnext);
                 }
             }
-            Body<RT> m2[NM], o2 = o;
-#pragma unroll
-            for (int i = 0; i < NM; ++i) m2[i] = m[i];
-            // mj_step (BE:1882): engine model gpr-push-v2
-            if constexpr (Math<RT>::literal) push_cycle<RT, NM>(Q, C.dt, m2, o2, qacc);
-            else push_cycle_fast<NM>(Q, C.dt, m2, o2, qacc);
+            // mj_step (BE:1882): engine model gpr-push-v2. An env that has collided stands still (BE:1904-1905): its lanes sit the
+            // cycle out (the votes inside push_cycle then only count the envs that still move, as they should)
             if (!frozen) {
-                o = o2;
+                if constexpr (Math<RT>::literal) push_cycle<RT, NM>(Q, C.dt, m, o, qacc);
+                else push_cycle_fast<NM>(Q, C.dt, m, o, qacc);
 #pragma unroll
-                for (int i = 0; i < NM; ++i) { m[i] = m2[i]; acc[i] = qacc[i]; }
+                for (int i = 0; i < NM; ++i) acc[i] = qacc[i];
             }
             bool w = false, hit = false;  // BE:1888-1901
 #pragma unroll

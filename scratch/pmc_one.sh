@@ -2,7 +2,7 @@
 # usage: pmc_one.sh "<one.py args>" tag -- SQ instruction counters of the step kernel for one configuration
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_one_$2; rm -rf $O; mkdir -p $O
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F32 --kernel-trace --output-format csv -d $O/a -- python scratch/one.py $1 > /dev/null 2> $O/a.err
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F32 --kernel-trace --output-format csv -d $O/a -- python ${SCRIPT:-scratch/one.py} $1 > /dev/null 2> $O/a.err
 python - "$O" <<'PY'
 import csv, collections, glob, sys
 O=sys.argv[1]
