@@ -318,7 +318,7 @@ def main():
         'dtype': {'f32': 'f32', 'f32_f64acc': 'f32 storage / f64 arithmetic', 'f64': 'f64'}[args.precision], 'data': 'synthetic',
         'config': cfg,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0, false>',
+                     'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>',
                      'kernel_us': head['kernel_us'], 'algorithmic_bytes_per_env_step': B},
     }
 

@@ -393,7 +393,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
     auto draw_index = [&](int cycle, uint32_t which) { uint32_t q = S * (uint32_t)cycle + which; asm volatile("" : "+s"(q)); return q; };
     int next_c = 0;  // wave-uniform: the first cycle at which the speed clamp has to be looked at again
     // velocity-reading rows of this wavefront's needy lanes (see the clamp path); row 0 is all zeros
-    constexpr int VN_ROWS = 6;
+    constexpr int VN_ROWS = 12;
     __shared__ float2 vn_tab[BLOCK / 64][VN_ROWS + 1][64];
     const int vn_wave = (int)(threadIdx.x >> 6);
     vn_tab[vn_wave][0][__lane_id()] = make_float2(0.f, 0.f);
