@@ -17,7 +17,10 @@
 namespace gpr {
 
 constexpr uint32_t KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4;
-constexpr int BLOCK = 256;
+#ifndef GPR_BLOCK
+#define GPR_BLOCK 256
+#endif
+constexpr int BLOCK = GPR_BLOCK;  // threads per block of the step / reset / push kernels (a build-time experiment knob)
 
 // Scalar constants in the compute type. The host fills a float and a double copy so that a kernel reads its constants
 // straight from the kernarg segment into SGPRs (gfx950 has no scalar f64->f32 convert).
@@ -788,15 +791,29 @@ template <typename RT, int LPE, bool STRICT> __device__ __forceinline__ bool pai
 // ---------------------------------------------------------------------------------------------------------------------
 // ensure_max_dyn_val (PL:610-645) for one mover: returns the derivative to apply; `next` receives the next value
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename RT> __device__ __forceinline__ R2<RT> clamp_dyn(R2<RT> cur, RT max_value, R2<RT> deriv, RT dt, RT inv_dt, R2<RT> &next) {
+// a / b in parity mode, given rb = the correctly rounded 1 / b: product + one residual correction -- the sequence the compiler
+// emits for an IEEE division minus its reciprocal refinement and range scaling (12 instructions -> 3; the operands here are O(1)),
+// so quotients over a shared divisor (the clamp's norm; dt, whose reciprocal comes from the host) cost one reciprocal together.
+template <typename RT> __device__ __forceinline__ RT div_rcp(RT a, RT b, RT rb) {
+    if constexpr (Math<RT>::literal) { const RT q = a * rb; return fma(fma(-q, b, a), rb, q); }
+    else return a * rb;
+}
+// (PLAIN: the stand-alone operator gpr_ensure_max_dyn_val takes arbitrary caller values -- it keeps the compiler's divisions)
+template <typename RT, bool PLAIN = false> __device__ __forceinline__ R2<RT> clamp_dyn(R2<RT> cur, RT max_value, R2<RT> deriv, RT dt, RT inv_dt, R2<RT> &next) {
     RT t0 = dt * deriv.x + cur.x, t1 = dt * deriv.y + cur.y;  // PL:631
     RT n2 = t0 * t0 + t1 * t1;
     if constexpr (Math<RT>::literal) {
         RT norm = sqrt(n2);  // PL:633
         if (norm >= max_value) {  // PL:634, inclusive
-            next.x = max_value * (t0 / norm);  // PL:640-642
-            next.y = max_value * (t1 / norm);
-            return R2<RT>{(next.x - cur.x) / dt, (next.y - cur.y) / dt};  // PL:643
+            if constexpr (PLAIN) {
+                next.x = max_value * (t0 / norm);
+                next.y = max_value * (t1 / norm);
+                return R2<RT>{(next.x - cur.x) / dt, (next.y - cur.y) / dt};
+            }
+            const RT rn = (RT)1 / norm;  // (four quotients over two divisors: div_rcp)
+            next.x = max_value * div_rcp<RT>(t0, norm, rn);  // PL:640-642
+            next.y = max_value * div_rcp<RT>(t1, norm, rn);
+            return R2<RT>{div_rcp<RT>(next.x - cur.x, dt, inv_dt), div_rcp<RT>(next.y - cur.y, dt, inv_dt)};  // PL:643
         }
         next.x = t0; next.y = t1;
         return deriv;

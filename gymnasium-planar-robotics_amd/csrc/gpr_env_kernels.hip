@@ -760,8 +760,8 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                 R2<RT> acc_p = clamp_dyn<RT>(vn, C.v_max, acc_tmp, C.dt, C.inv_dt, vnext);
                 bool diff = (acc_tmp.x != acc_p.x) | (acc_tmp.y != acc_p.y);
                 R2<RT> u;
-                u.x = diff ? (acc_p.x - acc.x) / C.dt : j1.x;
-                u.y = diff ? (acc_p.y - acc.y) / C.dt : j1.y;
+                u.x = diff ? div_rcp<RT>(acc_p.x - acc.x, C.dt, C.inv_dt) : j1.x;
+                u.y = diff ? div_rcp<RT>(acc_p.y - acc.y, C.dt, C.inv_dt) : j1.y;
                 // mj_step with dyntype=integrator, actearly (PL:307-310): act += dt*ctrl, qacc = act_new
                 qacc.x = acc.x + C.dt * u.x;
                 qacc.y = acc.y + C.dt * u.y;

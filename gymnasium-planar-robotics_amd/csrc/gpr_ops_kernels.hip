@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(BLOCK) k_clamp(int64_t n, const double *cur, c
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     R2<double> nx;
-    R2<double> d = clamp_dyn<double>(R2<double>{cur[2 * i], cur[2 * i + 1]}, maxv[i], R2<double>{der[2 * i], der[2 * i + 1]}, dt, 1.0 / dt, nx);
+    R2<double> d = clamp_dyn<double, true>(R2<double>{cur[2 * i], cur[2 * i + 1]}, maxv[i], R2<double>{der[2 * i], der[2 * i + 1]}, dt, 1.0 / dt, nx);
     vals[2 * i] = nx.x; vals[2 * i + 1] = nx.y;
     ders[2 * i] = d.x; ders[2 * i + 1] = d.y;
 }

@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                     const R2<RT> j1 = clamp_dyn<RT>(acc[i], C.a_max, a[i], C.dt, C.inv_dt, acc_tmp);
                     const R2<RT> acc_p = clamp_dyn<RT>(vn, C.v_max, acc_tmp, C.dt, C.inv_dt, vnext);
                     const bool diff = (acc_tmp.x != acc_p.x) | (acc_tmp.y != acc_p.y);
-                    const R2<RT> uu{diff ? (acc_p.x - acc[i].x) / C.dt : j1.x, diff ? (acc_p.y - acc[i].y) / C.dt : j1.y};
+                    const R2<RT> uu{diff ? div_rcp<RT>(acc_p.x - acc[i].x, C.dt, C.inv_dt) : j1.x, diff ? div_rcp<RT>(acc_p.y - acc[i].y, C.dt, C.inv_dt) : j1.y};
                     qacc[i].x = acc[i].x + C.dt * uu.x; qacc[i].y = acc[i].y + C.dt * uu.y;
                 } else {
                     qacc[i] = clamp_dyn<RT>(vn, C.v_max, a[i], C.dt, C.inv_dt, vnext);
