@@ -118,7 +118,12 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
                 const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
                 if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
                 else w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
-                if (pass == 0) hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
+                if (pass == 0) {  // a candidate set is axis-aligned: bounding boxes decide, the 16 segment tests per pair only in a sliver
+                    bool sure = false, unsure = false;
+                    AabbSweep<RT, LPE, 1>::run(cn.x, cn.y, ps0, ps1, sure, unsure);
+                    if (__ballot(live & unsure) == 0ull) hit = live & sure;
+                    else hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
+                }
                 else hit = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);
             }
             const bool bad = group_any<LPE>(w | hit);
