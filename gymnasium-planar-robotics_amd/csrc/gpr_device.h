@@ -687,17 +687,18 @@ template <typename RT, int LPE, int D> struct BoxNearMetric {
 // of two such rectangles cross iff their bounding boxes -- themselves -- overlap and neither lies inside the other, and the
 // distance pre-filter BE:411-414 (4 x the larger half size) always holds for overlapping ones. `sure`: some partner surely
 // intersects; `unsure`: some partner is within 2e-6 of touching or of lying inside (GEO:107-138 compares with 1e-7 tolerances) --
-// then the caller runs the general test. s0, s1: this lane's half sizes (with whatever offset the check uses).
+// then the caller runs the general test. s0, s1: this lane's half sizes (with whatever offset the check uses). With eps = what two
+// noisy reads can add to / take from the gap, `sure` and "neither" hold for every possible pair of reads (the step loop's lazy noise).
 template <typename RT, int LPE, int D> struct AabbSweep {
-    static __device__ __forceinline__ void run(RT x, RT y, RT s0, RT s1, bool &sure, bool &unsure) {
+    static __device__ __forceinline__ void run(RT x, RT y, RT s0, RT s1, bool &sure, bool &unsure, RT eps = (RT)2e-6) {
         if constexpr (D <= LPE / 2 && D >= 1 && LPE > 1) {
             const RT adx = absr(x - rot<LPE, D>(x)), ady = absr(y - rot<LPE, D>(y));
-            const RT o0 = rot<LPE, D>(s0), o1 = rot<LPE, D>(s1), eps = (RT)2e-6;
+            const RT o0 = rot<LPE, D>(s0), o1 = rot<LPE, D>(s1);
             const RT gap = fmax(adx - (s0 + o0), ady - (s1 + o1));  // < 0: the rectangles overlap
             const bool inside = (adx + fmin(s0, o0) < fmax(s0, o0) + eps) & (ady + fmin(s1, o1) < fmax(s1, o1) + eps);
             sure |= (gap < -eps) & !inside;
             unsure |= (absr(gap) <= eps) | ((gap < -eps) & inside);
-            AabbSweep<RT, LPE, D + 1>::run(x, y, s0, s1, sure, unsure);
+            AabbSweep<RT, LPE, D + 1>::run(x, y, s0, s1, sure, unsure, eps);
         }
     }
 };

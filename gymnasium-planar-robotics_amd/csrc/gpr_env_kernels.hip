@@ -520,8 +520,17 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                     wraw = __ballot(!pos_valid_box<RT, false>(T, P, qn, bw0, bw1, (RT)0, nullptr));
                 }
                 if (every | ((__ballot(near_b) & act) != 0ull)) {
-                    const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u + R));
-                    hraw = __ballot(box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr));
+                    // three zones on the noise-free (axis-aligned) rectangles: overlapping by more than two reads can undo -> a hit
+                    // whatever is read (a mover moves up to 2 mm per cycle, the band is 0.1 mm wide: the usual collision); within
+                    // the band -> the noisy read and the rectangle tests decide; apart by more -> nothing
+                    bool sure = false, unsure = false;
+                    AabbSweep<RT, LPE, 1>::run(q.x, q.y, c, c1, sure, unsure, (RT)2 * band_b + (RT)2e-6);
+                    if (!every & ((__ballot(unsure) & act) == 0ull)) {
+                        hraw = __ballot(sure);
+                    } else {
+                        const Pose<RT> qn = noisy_pose<RT, true>(p, C.sig_p, key, draw_index(cyc, 1u + R));
+                        hraw = __ballot(box_pair_hit<RT, LPE>(qn, c, c1, (RT)0, true, nullptr));
+                    }
                 }
             } else {
                 if ((__ballot(near_b) & act) != 0ull) hraw = __ballot(box_pair_hit<RT, LPE>(Pose<RT>{p.x, p.y, (RT)1, (RT)0, (RT)0, (RT)0}, c, c1, (RT)0, true, nullptr));
