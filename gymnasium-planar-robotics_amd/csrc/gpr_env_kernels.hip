@@ -370,6 +370,37 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         : CircleSize<RT>{bw0, (RT)0, (RT)0, (RT)0.5 * (C.gx1 - C.gx0) - bw0, (RT)0.5 * (C.gy1 - C.gy0) - bw1};
     const RT band_w = SHAPE == 0 ? C.band_p : band_b;
     RT wx_l = cw_thr.wx;                                   // wall: valid iff reach < wx_l (full grid)
+    // LAYOUTS WITH HOLES (circles): the block loop's wall pre-test against a per-lane FREE BOX instead of the grid -- the largest
+    // rectangle of existing tiles inside the 3x3 neighbourhood of the tile the mover starts the step above that leaves the start
+    // position the most room (T.nbr). A circle smaller than half a tile whose bounding box lies inside such a
+    // rectangle only ever sees existing tiles, and BE:459-788 then finds no missing neighbour on any side it reaches over: valid,
+    // exactly as on a grid without holes. Positions outside the box prove nothing: their blocks are replayed through exact_cycle's
+    // table-driven test (what every cycle of such a layout went through before). fb_x / fb_y: the box's centre relative to the
+    // grid's, fb_k: half width minus half height.
+    RT fb_x = (RT)0, fb_y = (RT)0, fb_k = cw_thr.wx - cw_thr.wy;
+    if constexpr (!FULL) {
+        const int ix = clampi(Math<RT>::floor_int(p0.x * C.inv_wx), 0, P.Tx - 1), iy = clampi(Math<RT>::floor_int(p0.y * C.inv_wy), 0, P.Ty - 1);
+        const uint32_t n = T.nbr[ix * P.Ty + iy];
+        const int xl = (n >> 1) & 1u ? -1 : 0, xr = (n >> 7) & 1u ? 1 : 0;
+        const bool usable = ((n >> 4) & 1u) & (cw_step.cfx < (RT)0.5) & (cw_step.cfy < (RT)0.5);
+        // every maximal rectangle of existing tiles around the centre tile has one of four x ranges and, for it, the rows that exist
+        // over the whole range; the one in which the start position has the most room is the lane's free box
+        RT best = -INF, hx_b = (RT)-1;
+        auto candidate = [&](int cxl, int cxr) {
+            const uint32_t row_dn = (cxl ? 1u : 0u) | 8u | (cxr ? 64u : 0u), row_up = row_dn << 2;  // bit (dx + 1) * 3 + (dy + 1)
+            const int yl = (n & row_dn) == row_dn ? -1 : 0, yr = (n & row_up) == row_up ? 1 : 0;
+            const RT x_lo = T.ax[4 * (ix + cxl)], x_hi = T.ax[4 * (ix + cxr) + 1], y_lo = T.ay[4 * (iy + yl)], y_hi = T.ay[4 * (iy + yr) + 1];
+            const RT hx = (RT)0.5 * (x_hi - x_lo) - cw_step.c, hy = (RT)0.5 * (y_hi - y_lo) - cw_step.c;
+            const RT mx = (RT)0.5 * (x_lo + x_hi), my = (RT)0.5 * (y_lo + y_hi);
+            const RT room = __builtin_fminf(hx - __builtin_fabsf(p0.x - mx), hy - __builtin_fabsf(p0.y - my));
+            if (room > best) {
+                best = room; hx_b = hx; fb_k = hx - hy;
+                fb_x = mx - (RT)0.5 * (C.gx0 + C.gx1); fb_y = my - (RT)0.5 * (C.gy0 + C.gy1);
+            }
+        };
+        candidate(xl, xr); candidate(xl, 0); candidate(0, xr); candidate(0, 0);
+        wx_l = usable ? hx_b : (RT)-1;
+    }
     RT w0 = every ? -INF : wx_l - band_w;                   // certainly valid, whatever the noise, iff reach < w0
     const RT wband = every ? INF : band_w;
     const RT pb = C.max_csum_step + band_pair;
@@ -594,7 +625,11 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
     GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
     constexpr int KB = 4;
     static_assert(KC1 == KB - 1, "the first rung covers exactly one block");
-    const bool fast_ok = FULL && !every;
+    const bool fast_ok = !every;
+    auto block_reach = [&](RT qx, RT qy) -> RT {  // the block's wall pre-test: grid without holes / free box (see fb_x)
+        if constexpr (FULL) return wall_reach_centred<RT>(qx, qy, cw_thr);
+        else return __builtin_fmaxf(__builtin_fabsf(qx - fb_x), __builtin_fabsf(qy - fb_y) + fb_k);
+    };
     // the block's pair pre-test per cycle, ONE number per lane: circles: the smallest squared pair distance (near iff <= p0r); boxes:
     // the smallest over the partners of max(|dx| - bnx, |dy| - bny) (near iff <= 0: some partner's inflated bounding box overlaps)
     auto pair_reach = [&](RT qx, RT qy) -> RT {
@@ -627,7 +662,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                         integrate(R2<RT>{dv.x + dtl.x, dv.y + dtl.y});
                         const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
                         dps[j] = dp; dvs[j] = dv;
-                        es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
+                        es[j] = block_reach(q.x, q.y);
                         eacc = __builtin_fmaxf(eacc, es[j]);
                         ms[j] = INF;
                         if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
@@ -647,7 +682,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                         integrate(clamp_dv(t, nv, speed2(t), dvn));
                         const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
                         dps[j] = dp; dvs[j] = dv;
-                        es[j] = wall_reach_centred<RT>(q.x, q.y, cw_thr);
+                        es[j] = block_reach(q.x, q.y);
                         eacc = __builtin_fmaxf(eacc, es[j]);
                         ms[j] = INF;
                         if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
@@ -655,7 +690,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
                 }
                 // (the near limit of a lane that is out -- dead, padding, frozen -- is -1: never reached; bnx is its flag for boxes)
                 const bool flagged = (__ballot(!(eacc < w0)) | __ballot(macc <= (SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1)))) != 0ull;
-                if (SHAPE == 1 && flagged) {
+                if ((SHAPE == 1 || !FULL) && flagged) {
                     // box shape: the exact rectangle tests (rotated vertices, table walk, 16 segment pairs per rectangle pair) are
                     // long; instead of one copy of them per cycle of the block, the block is taken back and replayed through
                     // exact_cycle (ONE copy, in the loop below)

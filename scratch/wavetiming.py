@@ -6,7 +6,9 @@ import gymnasium_planar_robotics_amd as gpr
 E, M = int(os.environ.get('WT_ENVS', 65536)), int(os.environ.get('WT_MOVERS', 4))
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-5
 cp = {'shape': 'box', 'size': np.array([0.0775, 0.0775])} if (len(sys.argv) > 2 and sys.argv[2] == 'box') else None
-env = gpr.VecBenchmarkPlanningEnv(np.ones(({1:3,2:4,4:6,8:8,16:10}[M],) * 2), M, num_envs=E, std_noise=sigma, collision_params=cp, precision=os.environ.get('PREC', 'f32'))
+layout = np.ones(({1:3,2:4,4:6,8:8,16:10}[M],) * 2)
+if os.environ.get('WT_HOLES'): layout[2, 2] = 0; layout[3, 4] = 0
+env = gpr.VecBenchmarkPlanningEnv(layout, M, num_envs=E, std_noise=sigma, collision_params=cp, precision=os.environ.get('PREC', 'f32'))
 env.reset(seed=0)
 env.elapsed_steps.copy_(torch.randint(0, 50, (E,), device='cuda', dtype=torch.int32))
 acts = [(torch.rand(E, 2 * M, device='cuda') * 20 - 10).to(env.dtype) for _ in range(8)]
