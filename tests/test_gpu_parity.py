@@ -386,6 +386,38 @@ def test_sharding_invariance_and_determinism(gpr):
         assert torch.equal(ow[3], torch.cat([ol[3], oh[3]]))
 
 
+def test_free_box_blocks_match_cycle_by_cycle(gpr, monkeypatch):
+    """Layouts with holes: the block loop tests the wall against a per-lane free box (a rectangle of existing tiles around the start
+    tile) and replays flagged blocks through the table-driven test; GPR_EAGER_NOISE=1 runs that test in every cycle. A layout of
+    diagonal holes, an L-shaped corridor and a missing corner, circles just under half a tile: both must agree bit for bit, and
+    wall collisions next to the holes must actually occur."""
+    layout = np.array([[1, 1, 1, 1, 1, 0], [1, 0, 1, 1, 1, 1], [1, 1, 0, 1, 1, 1], [1, 1, 1, 1, 0, 1], [0, 1, 1, 1, 1, 1], [1, 1, 1, 0, 1, 1]])
+    for M, size in ((4, 0.11), (2, 0.1195), (3, 0.06)):
+        E = 16384
+        kw = dict(num_envs=E, std_noise=np.array([2e-5, 1e-5, 0.0]), collision_params={'shape': 'circle', 'size': size, 'offset': 0.0, 'offset_wall': 0.0})
+        monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
+        blocks = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
+        monkeypatch.setenv('GPR_EAGER_NOISE', '1')
+        cycles = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
+        monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
+        blocks.reset(seed=5); cycles.reset(seed=5)
+        assert torch.equal(blocks.pos, cycles.pos)
+        g = torch.Generator(device='cuda').manual_seed(9)
+        n_wall = 0
+        for step in range(40):
+            a = (torch.rand(E, 2 * M, device='cuda', generator=g) * 2 - 1) * blocks.a_max
+            ob = blocks.step(a); oc = cycles.step(a)
+            for k in ('observation', 'achieved_goal', 'desired_goal'):
+                assert torch.equal(ob[0][k], oc[0][k]), (M, step, k)
+            assert torch.equal(ob[1], oc[1]) and torch.equal(ob[2], oc[2]) and torch.equal(ob[3], oc[3])
+            assert torch.equal(ob[4]['wall_collision'], oc[4]['wall_collision']) and torch.equal(ob[4]['mover_collision'], oc[4]['mover_collision'])
+            assert torch.equal(blocks.pos, cycles.pos) and torch.equal(blocks.vel, cycles.vel)
+            n_wall += int(ob[4]['wall_collision'].sum())
+        assert n_wall > 1000, n_wall
+        record_metric(f'free_box_blocks[M{M}-r{size}]', env_steps=40 * E, wall_collisions=n_wall, mismatches=0)
+        blocks.close(); cycles.close()
+
+
 def test_lazy_noise_is_exact(gpr, monkeypatch):
     """The kernels skip a noise draw when no possible value of it could change the outcome of the comparison it feeds.
     GPR_EAGER_NOISE=1 (read at env creation) draws everything: both must produce bit-identical rollouts."""
