@@ -193,7 +193,7 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
     }
     // 2. contact geometry per pair (mover i, object), in mover i's frame
     struct Pair {
-        int np;
+        int np, npw;  // contact points of this env's pair; the most of any env of the wavefront (scalar: bounds the slot loops)
         float nx, ny;
         float rmn[PUSH_SLOTS], ron[PUSH_SLOTS], rmt[PUSH_SLOTS], rot_[PUSH_SLOTS];  // lever arms x n, x t
         float wmn[PUSH_SLOTS], won[PUSH_SLOTS], wmt[PUSH_SLOTS], wot[PUSH_SLOTS];   // ... times the inverse inertias
@@ -208,7 +208,7 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
     for (int i = 0; i < NM; ++i) {
         const Body<float> &m = mv[i];
         Pair &q = pr[i];
-        q.np = 0; q.nx = 0.f; q.ny = 0.f;
+        q.np = 0; q.npw = 0; q.nx = 0.f; q.ny = 0.f;
         const float dx = o.x - m.x, dy = o.y - m.y;
         const bool in_range = !(__builtin_fmaf(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
         if (__ballot(in_range) == 0ull) continue;
@@ -250,9 +250,12 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
         const int np_raw = __popc(mask);
         const int np = lone ? 1 : (np_raw < PUSH_SLOTS ? np_raw : PUSH_SLOTS);
         q.np = np; q.nx = nx; q.ny = ny;
+        // (one wave-level decision per pair and cycle instead of one per slot and sweep: the loops below are scalar-bounded)
+        const int npw = __ballot(np > 1) == 0ull ? 1 : __ballot(np > 2) == 0ull ? 2 : __ballot(np > 3) == 0ull ? 3 : 4;
+        q.npw = npw;
 #pragma unroll
         for (int k = 0; k < PUSH_SLOTS; ++k) {
-            if (__ballot(k < np) == 0ull) break;
+            if (k >= npw) break;
             const int idx = mask != 0u ? __builtin_ctz(mask) : 0;
             mask &= mask - 1u;
             const bool of_mover = idx >= 4;
@@ -286,7 +289,7 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
                 const float nmx = nx * Q.inv_mm, nmy = ny * Q.inv_mm, nox = nx * Q.inv_mo, noy = ny * Q.inv_mo;
 #pragma unroll
                 for (int k = 0; k < PUSH_SLOTS; ++k) {
-                    if (__ballot(k < q.np) == 0ull) break;
+                    if (k >= q.npw) break;
                     if (k < q.np) {
                         float dvx = o.vx - m.vx, dvy = o.vy - m.vy;
                         const float vn = __builtin_fmaf(dvx, nx, __builtin_fmaf(dvy, ny, __builtin_fmaf(o.w, q.ron[k], -(m.w * q.rmn[k]))));
