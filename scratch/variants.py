@@ -8,6 +8,8 @@ CFG = {
     'box': dict(E=65536, M=4, tiles=6, collision_params={'shape': 'box', 'size': np.array([0.0775, 0.0775])}),
     'f64': dict(E=65536, M=4, tiles=6, precision='f64'), 'f64acc': dict(E=65536, M=4, tiles=6, precision='f32_f64acc'),
     'jerk': dict(E=65536, M=4, tiles=6, precision='f64', learn_jerk=True), 'holes': dict(E=65536, M=4, tiles=6, holes=True),
+    # per-GPU shards of BASELINE configs 4 and 5 on 8 GPUs, and config 2
+    'm8s': dict(E=8192, M=8, tiles=8), 'm16s': dict(E=4096, M=16, tiles=10), 'm4s': dict(E=4096, M=4, tiles=6),
 }
 for name in (sys.argv[1:] or ['m4', 'box', 'f64']):
     kw = dict(CFG[name]); E, M, tiles = kw.pop('E'), kw.pop('M'), kw.pop('tiles')
