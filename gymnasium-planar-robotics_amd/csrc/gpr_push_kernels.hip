@@ -3,8 +3,9 @@
 //
 // Pinned by the reference: control + clamp (PU:419-448), wall check (BE:426-788), obs / info / reward / terminated (PU:457-607),
 // reset sampling (PU:373-417). The contact physics is the engine's own planar model "gpr-push-v2" (parity unpinned: the
-// reference hands it to MuJoCo) -- see include/gpr.h and DESIGN.md section 9; oracle/gpr_oracle.c:push_cycle is the same model,
-// operation for operation.
+// reference hands it to MuJoCo) -- see include/gpr.h and DESIGN.md section 9. The double builds run push_cycle, which is
+// oracle/gpr_oracle.c:push_cycle operation for operation (1e-9 on every state in the tests); the float build runs
+// push_cycle_fast, the same model written for the fewest instructions (equal up to float rounding).
 //
 // Everything a cycle touches lives in registers: the contact points of a pair are at most PUSH_SLOTS entries of fixed register
 // arrays (written through unrolled selects, never indexed dynamically -- the first version kept them in scratch memory and
@@ -28,8 +29,8 @@ template <typename RT> struct PushPair {
 
 template <typename RT> __device__ __forceinline__ RT cross2(RT ax, RT ay, RT bx, RT by) { return ax * by - ay * bx; }
 
-// one control cycle of the NM movers and the object (mirrors oracle/gpr_oracle.c push_cycle operation for operation; the float
-// build takes its quotients through v_rcp_f32 and its sines / cosines from v_sin_f32 / v_cos_f32)
+// one control cycle of the NM movers and the object: oracle/gpr_oracle.c push_cycle operation for operation (the double builds;
+// instantiated for float too, where push_cycle_fast below is what runs)
 template <typename RT, int NM>
 __device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT> (&mv)[NM], Body<RT> &o, const R2<RT> (&u)[NM]) {
     // 1. external forces
