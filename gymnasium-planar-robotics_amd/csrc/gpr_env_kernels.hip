@@ -226,8 +226,24 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 // -----------------------------------------------------------------------------------------------------------------
 // One env-step of every env of the block. MULTI (gpr_step_n): the block calls it once per step with that step's parameter block
 // (`first`: the first step of the launch), wavefronts reset their own envs and never wait for each other.
+// What a wavefront of gpr_step_n keeps in registers from one step of the launch to the next: its envs' state as it was stored
+// (a reset env's as its reset left it), the next step's actions (loaded a whole step ahead) and the per-lane constants --
+// a step then starts computing at once instead of waiting for its own stores to come back through L2.
+template <typename RT> struct StepCarry {
+    R2<RT> p, v, g, acc, a_next;
+    RT c, c1;
+    int el;
+    uint32_t cnt;
+};
+// the value lane `lane` holds (per-lane source)
+__device__ __forceinline__ float lane_fetch(float v, int lane) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)__float_as_uint(v))); }
+__device__ __forceinline__ double lane_fetch(double v, int lane) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI>
-__device__ __forceinline__ void step_body(const KParams &P, bool first) {
+__device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarry<RT> *carry = nullptr, const void *next_action = nullptr) {
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
@@ -272,20 +288,33 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
     };
 
     // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
-    R2<RT> a = load2<ST, RT>(P.action, idx);
-    R2<RT> p = load2<ST, RT>(P.pos, idx);
-    R2<RT> v = load2<ST, RT>(P.vel, idx);
-    R2<RT> g = load2<ST, RT>(P.goal, idx);
-    R2<RT> acc{(RT)0, (RT)0};
-    if constexpr (JERK) acc = load2<ST, RT>(P.acc, idx);
-    int el = P.elapsed[envc];
+    // (gpr_step_n after its first step: nothing is read -- the wavefront carried it over in registers, see StepCarry)
+    const bool carried = MULTI && !first && carry != nullptr;
+    R2<RT> a, p, v, g, acc{(RT)0, (RT)0};
+    int el;
     // episode counters (include/gpr.h: GPR_CNT_*): lanes 0..5 of a wavefront own the six words of the wavefront's row
     uint32_t cnt_old = 0u;
     const int64_t cnt_row = t >> 6;
-    if ((P.counters != nullptr) & (__lane_id() < 6u)) cnt_old = P.counters[cnt_row * 6 + __lane_id()];
+    RT c, c1;
+    if (carried) {
+        a = carry->a_next; p = carry->p; v = carry->v; g = carry->g; acc = carry->acc; el = carry->el; cnt_old = carry->cnt;
+        c = carry->c; c1 = carry->c1;
+    } else {
+        a = load2<ST, RT>(P.action, idx);
+        p = load2<ST, RT>(P.pos, idx);
+        v = load2<ST, RT>(P.vel, idx);
+        g = load2<ST, RT>(P.goal, idx);
+        if constexpr (JERK) acc = load2<ST, RT>(P.acc, idx);
+        el = P.elapsed[envc];
+        if ((P.counters != nullptr) & (__lane_id() < 6u)) cnt_old = P.counters[cnt_row * 6 + __lane_id()];
+        c = make_tables<RT>(P.tables, P).csz[2 * mvc];       // per-mover size straight from the (L2-resident) device table
+        c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
+    }
+    if (MULTI && carry != nullptr) {
+        if (next_action != nullptr) carry->a_next = load2<ST, RT>(next_action, idx);  // consumed a whole step from now
+        carry->c = c; carry->c1 = c1;
+    }
     if (mv >= M) { p.x = p.y = far_away<RT>(); v.x = v.y = (RT)0; a.x = a.y = (RT)0; acc.x = acc.y = (RT)0; }  // group padding
-    const RT c = make_tables<RT>(P.tables, P).csz[2 * mvc];  // per-mover size straight from the (L2-resident) device table
-    const RT c1 = make_tables<RT>(P.tables, P).csz[2 * mvc + 1];  // box: second half size
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
     if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) {  // (the box functions and the literal checks read the tables)
         if (!MULTI || first) stage_tables(lds, P.tables, P.table_bytes);
@@ -1053,6 +1082,10 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         const uint32_t L = __lane_id();
         const uint32_t add = L == 0u ? c0 : L == 1u ? c1 : L == 2u ? c2 : L == 3u ? c3 : L == 4u ? c4 : c5;
         if (L < 6u) P.counters[cnt_row * 6 + L] = cnt_old + add;
+        if (MULTI && carry != nullptr) carry->cnt = cnt_old + add;
+    }
+    if (MULTI && carry != nullptr) {  // the state the next step of this launch starts from (reset envs: overwritten below)
+        carry->p = p; carry->v = v; carry->acc = acc; carry->g = g; carry->el = el_new;
     }
 
     // What the stepping wavefront stores: everything of the envs that go on, and of an env that ended in this call its
@@ -1084,10 +1117,10 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
     constexpr int GROUPS = 64 / LPE;
     GPR_WT(const long long wt1 = __builtin_amdgcn_s_memtime();)
     // one claim: n envs, S lane groups each; lane group gi works for claim slot gi / S on env `renv`
-    auto serve = [&](int n, int S, bool have, int64_t renv, bool rfirst) __attribute__((always_inline)) {
+    auto serve = [&](int n, int S, bool have, int64_t renv, bool rfirst, R2<RT> &rp, R2<RT> &rg) __attribute__((always_inline)) {
         const int gi = (int)(threadIdx.x & 63) / LPE;
         const bool rlive = have & (mv < M);
-        R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+        rp = R2<RT>{(RT)0, (RT)0}; rg = R2<RT>{(RT)0, (RT)0};
         bool rwc, rmc;
         const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc);
         if (rlive & ((gi & (S - 1)) == 0)) {  // one group of the env's set stores
@@ -1110,6 +1143,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         unsigned long long todo = __ballot(need & (mv == 0));           // one bit per needy env: lane gi * LPE
         const unsigned long long rf_m = __ballot(reset_first & (mv == 0));
         while (todo != 0ull) {
+            const unsigned long long claim = todo;
             int n = __popcll(todo);
             n = n < EPW ? n : EPW;
             int S = 1;
@@ -1126,7 +1160,17 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
             const bool have = eslot < n;
             const bool rfirst = ((rf_m >> (tgt * LPE)) & 1ull) != 0ull;
             GPR_WT(wt_served += n;)
-            serve(n, S, have, env_w0 + tgt, rfirst);
+            R2<RT> rp, rg;
+            serve(n, S, have, env_w0 + tgt, rfirst, rp, rg);
+            if (carry != nullptr) {
+                // the new state goes to the env's own lanes: the r-th needy group of `claim` was served by the lane groups
+                // r * S .. r * S + S - 1, every one of which holds the result (mover mv in lane mv of the group)
+                const int bit = gi * LPE, my_r = __popcll(claim & ((1ull << bit) - 1ull));
+                const bool mine = (((claim >> bit) & 1ull) != 0ull) & (my_r < n);
+                const int src = (my_r < n ? my_r : 0) * S * LPE + mv;
+                const R2<RT> hp{lane_fetch(rp.x, src), lane_fetch(rp.y, src)}, hg{lane_fetch(rg.x, src), lane_fetch(rg.y, src)};
+                if (mine) { carry->p = hp; carry->g = hg; carry->v = R2<RT>{(RT)0, (RT)0}; carry->acc = R2<RT>{(RT)0, (RT)0}; }
+            }
         }
     } else {
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1159,7 +1203,8 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first) {
         const bool have = eslot < n;
         int entry;
         do { entry = __hip_atomic_load(&reset_list[base + (have ? eslot : 0)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
-        serve(n, S, have, env_block_base + (entry >> 1), (entry & 1) != 0);
+        R2<RT> rp, rg;
+        serve(n, S, have, env_block_base + (entry >> 1), (entry & 1) != 0, rp, rg);
     }
     }
 #ifdef GPR_WAVE_TIMING
@@ -1187,15 +1232,12 @@ __global__ void __launch_bounds__(BLOCK, (Math<RT>::literal && SHAPE == 0 && FUL
 // registers cost 40 VGPRs and a wavefront per SIMD), so the n steps are bit for bit the n calls of gpr_step.
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
 __global__ void __launch_bounds__(BLOCK) k_step_n(const KParams *__restrict__ steps, int n_steps) {
+    // a wavefront never reads back what it stored in an earlier step of the launch (StepCarry), and no other wavefront touches
+    // its envs: the steps need no fence between them, the stores drain while the next step computes
+    StepCarry<RT> carry;
     for (int st = 0; st < n_steps; ++st) {
-        if (st > 0) {
-            // this wavefront's stores of the previous step (its envs' state, incl. the resets it made for them) are complete before
-            // it reads that state again; no other wavefront touches its envs
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>(steps[st], st == 0);
+        const void *next_action = st + 1 < n_steps ? steps[st + 1].action : nullptr;
+        step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, true>(steps[st], st == 0, &carry, next_action);
     }
 }
 // -----------------------------------------------------------------------------------------------------------------
