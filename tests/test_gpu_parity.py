@@ -310,14 +310,26 @@ def test_step_reset_vs_oracle(gpr, oracle, cfg_i, precision):
     genv.close()
 
 
-def test_free_running_f64_matches_oracle_exactly(gpr, oracle):
+FREE_RUNNING_F64 = [
+    (np.ones((6, 6)), 4, {}),
+    (HOLES, 3, {'collision_params': {'shape': 'circle', 'size': 0.1, 'offset': 0.005, 'offset_wall': 0.002}}),  # table-driven wall test
+    (np.ones((5, 5)), 3, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.002}}),  # rectangle tests
+    (np.ones((6, 6)), 4, {'learn_jerk': True}),                                                         # two literal clamps per cycle
+    (np.ones((8, 8)), 8, {'std_noise': np.array([1e-4, 2e-4, 0.0])}),                                    # wide noise bands, 8 lanes per env
+]
+
+
+@pytest.mark.parametrize('cfg_i', range(len(FREE_RUNNING_F64)))
+def test_free_running_f64_matches_oracle_exactly(gpr, oracle, cfg_i):
     """no teacher forcing: 120 steps, every episode boundary, every auto-reset sample must agree with the oracle"""
-    layout, M, E = np.ones((6, 6)), 4, 256
-    genv, oenv = _make_pair(gpr, oracle, layout, M, E, 'f64', {})
+    layout, M, kw = FREE_RUNNING_F64[cfg_i]
+    E = 256
+    genv, oenv = _make_pair(gpr, oracle, layout, M, E, 'f64', kw)
     genv.reset(seed=7); oenv.reset(seed=7)
     rng = np.random.default_rng(3)
+    lim = genv.j_max if genv.learn_jerk else genv.a_max
     for step in range(120):
-        a = rng.uniform(-10, 10, size=(E, 2 * M))
+        a = rng.uniform(-lim, lim, size=(E, 2 * M))
         obs, rew, term, trunc, info = genv.step(torch.as_tensor(a, device=genv.device))
         o = oenv.step(a)
         assert np.array_equal(_g(term), o['terminated']) and np.array_equal(_g(trunc), o['truncated']), step
