@@ -343,13 +343,16 @@ def test_free_running_f64_matches_oracle_exactly(gpr, oracle, cfg_i):
     genv.close()
 
 
-@pytest.mark.parametrize('M,n,E', [(4, 6, 4096), (8, 8, 512), (16, 10, 128)])
+@pytest.mark.parametrize('M,n,E', [(4, 6, 4096), (8, 8, 512), (16, 10, 128), (4, 'box', 1024), (3, 'holes', 1024)])
 def test_free_running_f32_follows_the_oracle_within_1e_4(gpr, oracle, M, n, E):
     """The north-star statement, in the benchmark's precision and without teacher forcing: same seed, same actions, 100 steps
     (two full episodes, every auto-reset in between); every env is followed until the first env-step in which the float engine
     and the fp64 oracle decide differently -- which may only happen where the oracle itself had less than 1e-5 of room --
     and up to there every observation agrees within 1e-4."""
-    genv, oenv = _make_pair(gpr, oracle, np.ones((n, n)), M, E, 'f32', {})
+    layout, kw = (np.ones((n, n)), {}) if isinstance(n, int) else \
+        (np.ones((6, 6)), {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.002}}) if n == 'box' else \
+        (HOLES, {'collision_params': {'shape': 'circle', 'size': 0.1, 'offset': 0.005, 'offset_wall': 0.002}})
+    genv, oenv = _make_pair(gpr, oracle, layout, M, E, 'f32', kw)
     genv.reset(seed=21); oenv.reset(seed=21)
     rng = np.random.default_rng(8)
     alive = np.ones(E, dtype=bool)
@@ -373,7 +376,7 @@ def test_free_running_f32_follows_the_oracle_within_1e_4(gpr, oracle, M, n, E):
         worst = max(worst, float(err[alive].max(initial=0.0)))
         n_steps += int(alive.sum()); n_resets += int((o['terminated'] | o['truncated'])[alive].sum())
     assert alive.mean() > 0.99 and n_resets > E and worst < 1e-5, (alive.mean(), n_resets, worst)  # (measured: nobody leaves, worst 8e-7)
-    record_metric(f'free_running_f32[M{M}]', frac_envs_following_the_oracle=float(alive.mean()), max_obs_err=worst, tol=1e-4,
+    record_metric(f'free_running_f32[M{M}{"" if isinstance(n, int) else "-" + n}]', frac_envs_following_the_oracle=float(alive.mean()), max_obs_err=worst, tol=1e-4,
                   env_steps_followed=n_steps, auto_resets_followed=n_resets)
     genv.close()
 
