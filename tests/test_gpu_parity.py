@@ -375,7 +375,7 @@ def test_free_running_f32_follows_the_oracle_within_1e_4(gpr, oracle, M, n, E):
         alive &= same
         worst = max(worst, float(err[alive].max(initial=0.0)))
         n_steps += int(alive.sum()); n_resets += int((o['terminated'] | o['truncated'])[alive].sum())
-    assert alive.mean() > 0.99 and n_resets > E and worst < 1e-5, (alive.mean(), n_resets, worst)  # (measured: nobody leaves, worst 8e-7)
+    assert alive.mean() > 0.99 and n_resets > E and worst < 1e-5, (alive.mean(), n_resets, worst)  # (measured: nobody leaves, worst 4.3e-6)
     record_metric(f'free_running_f32[M{M}{"" if isinstance(n, int) else "-" + n}]', frac_envs_following_the_oracle=float(alive.mean()), max_obs_err=worst, tol=1e-4,
                   env_steps_followed=n_steps, auto_resets_followed=n_resets)
     genv.close()
