@@ -388,7 +388,11 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // does (the thresholds are then set so that every shortcut test fails) and the tests compare. Lanes that must not vote
     // (dead / padding lanes, frozen envs) are taken out through per-lane thresholds instead of scalar mask arithmetic.
     // ---------------------------------------------------------------------------------------------------------------
-    constexpr int KC1 = 3, KC2 = 11, KC3 = 39;  // rungs of the clamp ladder: 1, 3 and 10 blocks of KB = 4 cycles
+    // cycles per block of the block loop below: 8 where the per-cycle trace of a block fits the registers (4 lanes per env,
+    // circles: 127 of the 128 registers that keep 4 wavefronts per SIMD; one decision per 8 cycles: -2 % at 65 536 envs, -6 % at
+    // 4 096), else 4 (8 lanes per env: +10 % with blocks of 8; layouts with holes, whose flagged blocks are replayed: +8 %)
+    constexpr int KB = (LPE <= 4 && SHAPE == 0 && FULL) ? 8 : 4;
+    constexpr int KC1 = KB - 1, KC2 = 3 * KB - 1, KC3 = 39;  // rungs of the clamp ladder: 1 block, 3 blocks, 40 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
     // Box shape on a grid without holes: noise-free the rectangle is axis-aligned (identity quaternion), so its wall test is the
@@ -652,7 +656,6 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // wavefront run the block's clamp form, in which every lane evaluates PL:634-643 branch-free on its reading from LDS
     // (lanes without a row read zeros and cannot clamp).
     GPR_WT(wt_loop0 = __builtin_amdgcn_s_memtime();)
-    constexpr int KB = 4;
     static_assert(KC1 == KB - 1, "the first rung covers exactly one block");
     const bool fast_ok = !every;
     auto block_reach = [&](RT qx, RT qy) -> RT {  // the block's wall pre-test: grid without holes / free box (see fb_x)
@@ -1222,7 +1225,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
 }
 
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK, (Math<RT>::literal && SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step(const KParams P) {
+__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step(const KParams P) {
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:
@@ -1231,7 +1234,7 @@ __global__ void __launch_bounds__(BLOCK, (Math<RT>::literal && SHAPE == 0 && FUL
 // device memory through scalar loads, exactly as gpr_step's kernel reads the kernel argument segment (a per-step copy in
 // registers cost 40 VGPRs and a wavefront per SIMD), so the n steps are bit for bit the n calls of gpr_step.
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK) k_step_n(const KParams *__restrict__ steps, int n_steps) {
+__global__ void __launch_bounds__(BLOCK, (!Math<RT>::literal && SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step_n(const KParams *__restrict__ steps, int n_steps) {
     // a wavefront never reads back what it stored in an earlier step of the launch (StepCarry), and no other wavefront touches
     // its envs: the steps need no fence between them, the stores drain while the next step computes
     StepCarry<RT> carry;
