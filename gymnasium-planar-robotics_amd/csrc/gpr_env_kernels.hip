@@ -971,7 +971,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         // for them. Blocks of KB cycles, one decision per block, as in the throughput loop; cycles in which a lane may reach
         // the speed limit go through advance() one by one (its clamp is a sqrt and four divisions in double) -- and so does
         // every cycle of jerk mode (two clamps per cycle, PL:432-440), which still skips the literal checks of unflagged cycles.
-        constexpr int KB = 4;
+        constexpr int KB = 8;
         const float INFf = __builtin_huge_valf();
         const float cxf = (float)((RT)0.5 * (C.gx0 + C.gx1)), cyf = (float)((RT)0.5 * (C.gy0 + C.gy1));
         const float kwf = (float)(cw_step.wx - cw_step.wy);
