@@ -39,9 +39,12 @@ struct gpr_env {
     int lpe = 1;
     bool push_ready = false;
     size_t wave_timing_words = 0;
-    KParams *step_params = nullptr;  // gpr_step_n: device array of per-step parameter blocks (grown on demand)
-    int step_params_cap = 0;
-    std::vector<KParams> step_params_host;
+    int device = 0;  // the HIP device the handle was created on: every call must be made with it current
+    // gpr_step_n: per-step parameter blocks. Two slots used in turn, each a pinned host array, a device array and an event recorded
+    // behind the launch that reads the slot: a slot is rewritten only after that launch is complete, whatever stream it ran on
+    struct StepSlot { KParams *host = nullptr, *dev = nullptr; hipEvent_t done = nullptr; int cap = 0; bool busy = false; };
+    StepSlot step_slots[2];
+    int step_slot_next = 0;
     uint32_t *counters = nullptr;  // [waves][GPR_NUM_COUNTERS] per-wavefront episode counters (gpr_enable_counters)
     size_t counter_rows = 0;
     bool counters_on = false;
@@ -221,6 +224,18 @@ hipError_t ensure_normal_tables() {
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
+// The handle's tables, counters and kernel attributes live on ONE device; launching from a thread whose current device is another
+// one would run the kernel there on pointers it cannot reach. Refuse instead of faulting.
+int check_device(gpr_env *e, const char *who) {
+    int dev = -1;
+    const hipError_t he = hipGetDevice(&dev);
+    if (he != hipSuccess) return fail_hip(e, he, who);
+    if (dev != e->device)
+        return fail(e, GPR_E_INVALID, std::string(who) + ": the handle was created on device " + std::to_string(e->device) + " but device " +
+                                          std::to_string(dev) + " is current (hipSetDevice / torch.cuda.device before the call)");
+    return GPR_OK;
+}
+
 KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
     KParams P = e->base;
     const TableSet &ts = (is_f64_ops || e->cfg.precision != GPR_PRECISION_F32 || e->cfg.learn_jerk) ? e->tab_f64 : e->tab_f32;
@@ -254,6 +269,7 @@ int check_out(gpr_env *e, const gpr_step_out *o) {
 }
 
 int launch_env(gpr_env *e, bool is_reset, const KParams &P, hipStream_t s) {
+    if (const int rc = check_device(e, is_reset ? "gpr_reset" : "gpr_step")) return rc;
     hipError_t he;
     switch (e->cfg.precision) {
         case GPR_PRECISION_F32:
@@ -290,6 +306,7 @@ template <typename RT> void fill_push(const gpr_env &e, const gpr_push_params &p
 }
 
 int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, const void *opt_start = nullptr, const void *opt_goal = nullptr) {
+    if (const int rc = check_device(env, is_reset ? "gpr_push_reset" : "gpr_push_step")) return rc;
     hipError_t he;
     PushPtrs X = env->push_ptrs;
     X.opt_start = opt_start; X.opt_goal = opt_goal;
@@ -342,6 +359,7 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     }
     gpr_env *e = new gpr_env();
     e->cfg = c;
+    (void)hipGetDevice(&e->device);
     e->layout.assign(c.layout_tiles, c.layout_tiles + (size_t)c.num_tiles_x * c.num_tiles_y);
     e->xc = c.tile_x_centres ? std::vector<double>(c.tile_x_centres, c.tile_x_centres + c.num_tiles_x) : tile_centres(c.num_tiles_x, c.tile_half_size[0]);
     e->yc = c.tile_y_centres ? std::vector<double>(c.tile_y_centres, c.tile_y_centres + c.num_tiles_y) : tile_centres(c.num_tiles_y, c.tile_half_size[1]);
@@ -410,7 +428,12 @@ void gpr_destroy(gpr_env *env) {
     }
 #endif
     if (env->counters) (void)hipFree(env->counters);
-    if (env->step_params) (void)hipFree(env->step_params);
+    for (auto &sl : env->step_slots) {
+        if (sl.busy) (void)hipEventSynchronize(sl.done);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+    }
     if (env->tab_f32.dev) (void)hipFree(env->tab_f32.dev);
     if (env->tab_f64.dev) (void)hipFree(env->tab_f64.dev);
     delete env;
@@ -448,9 +471,12 @@ int gpr_set_rng_state(gpr_env *env, uint64_t seed, uint64_t tick) {
 
 int gpr_enable_counters(gpr_env *env, int32_t enable) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_enable_counters: NULL handle");
+    if (const int rc = check_device(env, "gpr_enable_counters")) return rc;
     if (enable && !env->counters) {
-        // one row per wavefront of the step kernel (planning: lpe lanes per env; pushing: one lane per env -- never more rows)
-        env->counter_rows = (size_t)((env->cfg.num_envs * env->lpe + 63) / 64);
+        // one row per wavefront of the step kernels' GRID -- whole blocks: the wavefronts of the last block that hold no env still
+        // read and write their (zero) rows. Planning: lpe lanes per env; pushing: PUSH_LANES lanes per env -- whichever is more.
+        const int64_t lanes = std::max<int64_t>(env->lpe, PUSH_LANES);
+        env->counter_rows = (size_t)((env->cfg.num_envs * lanes + BLOCK - 1) / BLOCK) * (size_t)(BLOCK / 64);
         const size_t bytes = env->counter_rows * GPR_NUM_COUNTERS * sizeof(uint32_t);
         hipError_t he = hipMalloc(reinterpret_cast<void **>(&env->counters), bytes);
         if (he != hipSuccess) { env->counters = nullptr; return fail_hip(env, he, "gpr_enable_counters: hipMalloc"); }
@@ -464,6 +490,7 @@ int gpr_enable_counters(gpr_env *env, int32_t enable) {
 int gpr_read_counters(gpr_env *env, uint64_t *totals_dev, void *hip_stream) {
     if (!env || !totals_dev) return fail(env, GPR_E_INVALID, "gpr_read_counters: NULL argument");
     if (!env->counters) return fail(env, GPR_E_UNBOUND, "gpr_read_counters: call gpr_enable_counters first");
+    if (const int rc = check_device(env, "gpr_read_counters")) return rc;
     hipError_t he = launch_counter_reduce(env->counters, (int64_t)env->counter_rows, totals_dev, as_stream(hip_stream));
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "counter reduce kernel launch");
 }
@@ -514,17 +541,27 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
     const int64_t sz = env->cfg.precision == GPR_PRECISION_F64 ? 8 : 4, obs_dim = 2 * M * (env->cfg.learn_jerk ? 2 : 1);
     const int64_t ss_action = E * 2 * M * sz, ss_obs = E * obs_dim * sz, ss_goal = E * 2 * M * sz, ss_reward = E * sz, ss_flag = E;
     // one parameter block per step: row i of every tensor, call counter tick + i
-    if (env->step_params_cap < n_steps) {
-        if (env->step_params) (void)hipFree(env->step_params);
-        env->step_params = nullptr; env->step_params_cap = 0;
-        hipError_t he = hipMalloc(reinterpret_cast<void **>(&env->step_params), sizeof(KParams) * (size_t)n_steps);
-        if (he != hipSuccess) return fail_hip(env, he, "gpr_step_n: hipMalloc");
-        env->step_params_cap = n_steps;
+    gpr_env::StepSlot &sl = env->step_slots[env->step_slot_next];
+    env->step_slot_next ^= 1;
+    if (sl.busy) {  // the launch that last read this slot (two calls ago) must be through before the slot is rewritten
+        const hipError_t he = hipEventSynchronize(sl.done);
+        if (he != hipSuccess) return fail_hip(env, he, "gpr_step_n: hipEventSynchronize");
+        sl.busy = false;
     }
-    env->step_params_host.assign((size_t)n_steps, P);
+    if (sl.cap < n_steps) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.host = sl.dev = nullptr; sl.cap = 0;
+        hipError_t he = hipHostMalloc(reinterpret_cast<void **>(&sl.host), sizeof(KParams) * (size_t)n_steps, hipHostMallocDefault);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&sl.dev), sizeof(KParams) * (size_t)n_steps);
+        if (he == hipSuccess && !sl.done) he = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        if (he != hipSuccess) return fail_hip(env, he, "gpr_step_n: parameter staging");
+        sl.cap = n_steps;
+    }
+    for (int i = 0; i < n_steps; ++i) sl.host[i] = P;
     auto adv = [](auto *&ptr, int64_t bytes) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<uintptr_t>(ptr) + (uintptr_t)bytes); };
     for (int i = 1; i < n_steps; ++i) {
-        KParams &Q = env->step_params_host[(size_t)i];
+        KParams &Q = sl.host[i];
         adv(Q.action, i * ss_action);
         adv(Q.obs, i * ss_obs); adv(Q.ag, i * ss_goal); adv(Q.dg, i * ss_goal); adv(Q.reward, i * ss_reward);
         adv(Q.terminated, i * ss_flag); adv(Q.truncated, i * ss_flag); adv(Q.is_success, i * ss_flag);
@@ -533,14 +570,17 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
         const uint64_t tick = env->tick + (uint64_t)i;
         Q.tick_lo = (uint32_t)tick; Q.tick_hi = (uint32_t)(tick >> 32);
     }
-    // (stream-ordered behind the previous launch that read the array; hipMemcpyAsync stages pageable memory before it returns)
-    hipError_t he = hipMemcpyAsync(env->step_params, env->step_params_host.data(), sizeof(KParams) * (size_t)n_steps, hipMemcpyHostToDevice,
-                                   as_stream(hip_stream));
+    // pinned source: a true asynchronous copy, ordered on the caller's stream in front of the launch that reads the device array
+    hipError_t he = hipMemcpyAsync(sl.dev, sl.host, sizeof(KParams) * (size_t)n_steps, hipMemcpyHostToDevice, as_stream(hip_stream));
     if (he != hipSuccess) return fail_hip(env, he, "gpr_step_n: parameter upload");
     P.n_steps = n_steps;
-    P.step_params = env->step_params;
+    P.step_params = sl.dev;
     rc = launch_env(env, false, P, as_stream(hip_stream));
-    if (rc == GPR_OK) env->tick += (uint64_t)n_steps;
+    if (rc == GPR_OK) {
+        env->tick += (uint64_t)n_steps;
+        if (hipEventRecord(sl.done, as_stream(hip_stream)) == hipSuccess) sl.busy = true;
+        else (void)hipStreamSynchronize(as_stream(hip_stream));  // (cannot track the launch: wait for it here)
+    }
     return rc;
 }
 
@@ -550,6 +590,7 @@ int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, co
     if (batch == 0) return GPR_OK;
     if (batch < 0 || !achieved_dev || !desired_dev || !mover_collision_dev || !wall_collision_dev || !reward_dev)
         return fail(env, GPR_E_INVALID, "gpr_compute_reward: bad argument");
+    if (const int drc = check_device(env, "gpr_compute_reward")) return drc;
     KParams P = make_params(env, nullptr, true);
     hipError_t he = env->cfg.precision == GPR_PRECISION_F64
                         ? launch_reward<double>(P, batch, achieved_dev, desired_dev, mover_collision_dev, wall_collision_dev, reward_dev, terminated_dev, as_stream(hip_stream))
@@ -565,6 +606,7 @@ int gpr_agent_views(gpr_env *env, const gpr_step_out *out, void *agent_obs_dev, 
     if (env->cfg.autoreset_mode == GPR_AUTORESET_SAME_STEP && !out->final_achieved_goal_dev)
         return fail(env, GPR_E_INVALID, "gpr_agent_views: same-step autoreset needs final_achieved_goal / final_desired_goal bound in `out` "
                                         "(the per-agent reward of an env that ended is computed from its terminal state)");
+    if (const int drc = check_device(env, "gpr_agent_views")) return drc;
     KParams P = make_params(env, out, true);
     const int obs_dim = env->cfg.num_movers * 2 * (env->cfg.learn_jerk ? 2 : 1);
     hipError_t he = env->cfg.precision == GPR_PRECISION_F64
@@ -624,6 +666,7 @@ int gpr_qpos_is_valid(gpr_env *env, int64_t n, const double *qpos_dev, const dou
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_qpos_is_valid: NULL handle");
     if (n == 0) return GPR_OK;
     if (n < 0 || !qpos_dev || !c_size_dev || !out_dev) return fail(env, GPR_E_INVALID, "gpr_qpos_is_valid: bad argument");
+    if (const int drc = check_device(env, "gpr_qpos_is_valid")) return drc;
     KParams P = make_params(env, nullptr, true);
     hipError_t he = launch_qpos_valid(P, n, qpos_dev, c_size_dev, add_safety_offset, out_dev, as_stream(hip_stream));
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "qpos_is_valid kernel launch");
@@ -634,6 +677,7 @@ int gpr_check_mover_collision(gpr_env *env, int64_t batch, const double *qpos_de
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_check_mover_collision: NULL handle");
     if (batch == 0) return GPR_OK;
     if (batch < 0 || !qpos_dev || !c_size_dev || !out_dev) return fail(env, GPR_E_INVALID, "gpr_check_mover_collision: bad argument");
+    if (const int drc = check_device(env, "gpr_check_mover_collision")) return drc;
     KParams P = make_params(env, nullptr, true);
     hipError_t he = launch_mover_collision(P, batch, qpos_dev, c_size_dev, add_safety_offset, out_dev, as_stream(hip_stream));
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "mover collision kernel launch");

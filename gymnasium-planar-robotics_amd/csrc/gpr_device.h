@@ -20,6 +20,7 @@ constexpr uint32_t KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 
 #ifndef GPR_BLOCK
 #define GPR_BLOCK 256
 #endif
+constexpr int PUSH_LANES = 1;  // lanes per env of the pushing kernels (gpr_push_kernels.hip)
 constexpr int BLOCK = GPR_BLOCK;  // threads per block of the step / reset / push kernels (a build-time experiment knob)
 
 // Scalar constants in the compute type. The host fills a float and a double copy so that a kernel reads its constants

@@ -1289,16 +1289,13 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     // the tile tables of a large layout (64 x 64 cells in f64: 47 KB) plus the kernels' static LDS exceed the 64 KB a launch
     // gets by default: raise the kernel's limit once (gfx950 has 160 KB per CU; gpr_create bounds the table size)
     if (lds > 32u * 1024u) {
-        static bool raised_reset = false, raised_step = false, raised_multi = false;
-        bool &raised = is_reset ? raised_reset : (P.n_steps > 1 ? raised_multi : raised_step);
-        if (!raised) {
-            const void *fn = is_reset ? reinterpret_cast<const void *>(&k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
-                                      : (P.n_steps > 1 ? reinterpret_cast<const void *>(&k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
-                                                       : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>));
-            const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-            if (he != hipSuccess) return he;
-            raised = true;
-        }
+        static bool raised[3][GPR_MAX_DEVICES];  // per (kernel, device): the attribute belongs to the device's code object
+        const int which = is_reset ? 0 : (P.n_steps > 1 ? 2 : 1);
+        const void *fn = is_reset ? reinterpret_cast<const void *>(&k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
+                                  : (P.n_steps > 1 ? reinterpret_cast<const void *>(&k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
+                                                   : reinterpret_cast<const void *>(&k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>));
+        const hipError_t he = raise_dynamic_lds(fn, 100 * 1024, raised[which]);
+        if (he != hipSuccess) return he;
     }
     if (is_reset) {
         hipLaunchKernelGGL((k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);

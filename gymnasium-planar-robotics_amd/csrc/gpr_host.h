@@ -4,6 +4,19 @@
 
 namespace gpr {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE attribute of a kernel: remember per (kernel, device) that it was
+// raised, and only once the call succeeded. `flags` is the kernel's own static array (zero-initialised).
+constexpr int GPR_MAX_DEVICES = 64;
+inline hipError_t raise_dynamic_lds(const void *fn, int bytes, bool (&flags)[GPR_MAX_DEVICES]) {
+    int dev = 0;
+    hipError_t he = hipGetDevice(&dev);
+    if (he != hipSuccess) return he;
+    if (dev >= 0 && dev < GPR_MAX_DEVICES && flags[dev]) return hipSuccess;
+    he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (he == hipSuccess && dev >= 0 && dev < GPR_MAX_DEVICES) flags[dev] = true;
+    return he;
+}
+
 // fused env kernels, one instantiation per (storage, compute) precision, each in its own translation unit
 template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s);
 

@@ -129,7 +129,10 @@ class RolloutBuffer:
                                                                      'terminated', 'truncated')) -> dict[str, torch.Tensor]:
         """ONE all-gather of the [T, num_envs, .] slice (local envs start .. start + num_envs) of the named fields: what a learner
         that samples ``world * num_envs`` envs per update reads. Returns per-field views [world, T, num_envs, ...]."""
-        key = (int(num_envs), tuple(fields))
+        num_envs, start = int(num_envs), int(start)
+        if not (num_envs >= 1 and 0 <= start and start + num_envs <= self.E):
+            raise ValueError(f'gather_minibatch: envs [{start}, {start + num_envs}) are not inside this rank\'s shard of {self.E} envs')
+        key = (num_envs, tuple(fields))
         if key not in self._mb:
             sizes = [int(self.views[f][:, :num_envs].numel() * self.views[f].element_size()) for f in fields]
             offs = [0]

@@ -317,6 +317,26 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         return tot
 
+    def _preprocess_info(self, info) -> tuple[torch.Tensor, torch.Tensor, bool]:
+        """``_preprocess_info_dict`` (PL:666-688, PU:670-689): the collision flags of a batch as uint8 device tensors. Accepts what the
+        reference accepts -- ONE info dict (batch of 1; the caller then returns a scalar like the reference's ``reward[0]``) or a NumPy
+        array / list / tuple of info dicts (what e.g. SB3's HER replay buffer passes) -- and, batched engine style, a dict whose values
+        are (batch,) tensors / arrays (what ``step()`` returns). -> (mover_collision, wall_collision, scalar)"""
+        if isinstance(info, (np.ndarray, list, tuple)):
+            items = list(np.asarray(info, dtype=object).reshape(-1)) if isinstance(info, np.ndarray) else list(info)
+            for it in items:
+                assert isinstance(it, dict) and 'wall_collision' in it, "every info dict needs the keys 'mover_collision' and 'wall_collision'"
+            flag = lambda it, k: bool(torch.as_tensor(it.get(k, False)).reshape(-1)[0]) if it.get(k) is not None else False  # noqa: E731
+            mc = torch.tensor([flag(it, 'mover_collision') for it in items], dtype=torch.uint8)
+            wc = torch.tensor([flag(it, 'wall_collision') for it in items], dtype=torch.uint8)
+            return mc.to(self.device), wc.to(self.device), False
+        assert isinstance(info, dict), 'info must be an info dict or an array / list of info dicts'
+        wc = torch.as_tensor(info['wall_collision'], device=self.device)
+        mc_in = info.get('mover_collision')
+        mc = torch.as_tensor(mc_in, device=self.device) if mc_in is not None else torch.zeros_like(wc)
+        scalar = wc.ndim == 0
+        return mc.reshape(-1).to(torch.uint8).contiguous(), wc.reshape(-1).to(torch.uint8).contiguous(), scalar
+
     def _dev_f64(self, a) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=torch.float64).contiguous()

@@ -211,12 +211,15 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         """PU:502-527 on batches (plain tensor algebra: three elementwise operations, no kernel of its own)."""
         ag = torch.as_tensor(achieved_goal, device=self.device).reshape(-1, 2).double()
         dg = torch.as_tensor(desired_goal, device=self.device).reshape(-1, 2).double()
-        wc = torch.as_tensor(info['wall_collision'], device=self.device).reshape(-1).bool()
-        if info.get('mover_collision') is not None:  # (two movers)
-            wc = wc | torch.as_tensor(info['mover_collision'], device=self.device).reshape(-1).bool()
+        mc, wc, scalar = self._preprocess_info(info)  # one info dict, an array / list of info dicts (PU:670-689), or a dict of tensors
+        wc = wc.bool()
+        if self.num_movers > 1:  # (two movers, engine-defined: their collision circles meeting ends the episode like a wall)
+            wc = wc | mc.bool()
+        assert wc.shape == (ag.shape[0],), 'achieved_goal and info disagree on the batch size'
         reached = (ag - dg).norm(dim=1) <= self.threshold_pos
         r = torch.where(wc, torch.full_like(reached, -50.0, dtype=torch.float64), torch.full_like(reached, -1.0, dtype=torch.float64))
-        return torch.where(reached & ~wc, torch.zeros_like(r), r).to(self.dtype)
+        r = torch.where(reached & ~wc, torch.zeros_like(r), r).to(self.dtype)
+        return r[0] if scalar else r
 
     def compute_terminated(self, achieved_goal, desired_goal, info) -> torch.Tensor:
         return self.compute_reward(achieved_goal, desired_goal, info) == self.reward_wall_collision  # PU:475

@@ -265,8 +265,10 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
             _native.check(self._lib.gpr_step_n(self._handle, T, actions.data_ptr(), C.byref(rollout['_out']), self._stream()), self._handle)
         return rollout
 
-    def compute_reward(self, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, info: dict[str, torch.Tensor]) -> torch.Tensor:
-        """Batched HER reward (PL:502-534). ``info`` holds 'mover_collision' and 'wall_collision' tensors of shape (batch,)."""
+    def compute_reward(self, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, info) -> torch.Tensor:
+        """Batched HER reward (PL:502-534). ``info``: a dict of 'mover_collision' / 'wall_collision' tensors of shape (batch,) (what
+        ``step()`` returns), or -- as in the reference (PL:666-688) -- an array / list of per-transition info dicts, or one info
+        dict of scalars (then a 0-dim tensor is returned, the reference's ``reward[0]``)."""
         return self._reward_and_terminated(achieved_goal, desired_goal, info)[0]
 
     def compute_terminated(self, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, info: dict[str, torch.Tensor]) -> torch.Tensor:
@@ -283,14 +285,14 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         ag = torch.as_tensor(achieved_goal, device=self.device).to(self.dtype).reshape(-1, 2 * M).contiguous()
         dg = torch.as_tensor(desired_goal, device=self.device).to(self.dtype).reshape(-1, 2 * M).contiguous()
         b = ag.shape[0]
-        mc = torch.as_tensor(info['mover_collision'], device=self.device).to(torch.uint8).reshape(b).contiguous()
-        wc = torch.as_tensor(info['wall_collision'], device=self.device).to(torch.uint8).reshape(b).contiguous()
+        mc, wc, scalar = self._preprocess_info(info)
+        assert mc.shape == (b,) and wc.shape == (b,) and dg.shape == ag.shape, 'achieved_goal, desired_goal and info disagree on the batch size'
         rew = torch.empty(b, dtype=self.dtype, device=self.device)
         term = torch.empty(b, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             _native.check(self._lib.gpr_compute_reward(self._handle, b, ag.data_ptr(), dg.data_ptr(), mc.data_ptr(), wc.data_ptr(),
                                                        rew.data_ptr(), term.data_ptr(), self._stream()), self._handle)
-        return rew, term.bool()
+        return (rew[0], term.bool()[0]) if scalar else (rew, term.bool())
 
     def ensure_max_dyn_val(self, current_values, max_value: float, next_derivs) -> tuple[torch.Tensor, torch.Tensor]:
         """``ensure_max_dyn_val`` (PL:610-645), row-wise on the device (f64): returns (next values, derivatives to apply)."""
