@@ -18,8 +18,8 @@ COUNTERS = ('episodes', 'terminated', 'truncated', 'success', 'wall_collision', 
 
 EXPORTS = (
     'gpr_version', 'gpr_last_error', 'gpr_create', 'gpr_destroy', 'gpr_bind_state', 'gpr_seed', 'gpr_get_rng_state', 'gpr_set_rng_state',
-    'gpr_reset', 'gpr_step', 'gpr_step_n', 'gpr_enable_counters', 'gpr_read_counters',
-    'gpr_compute_reward', 'gpr_agent_views', 'gpr_push_configure', 'gpr_push_reset', 'gpr_push_reset_opts', 'gpr_push_step', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
+    'gpr_reset', 'gpr_reset_candidates', 'gpr_step', 'gpr_step_n', 'gpr_enable_counters', 'gpr_read_counters',
+    'gpr_compute_reward', 'gpr_agent_views', 'gpr_push_configure', 'gpr_push_reset', 'gpr_push_reset_opts', 'gpr_push_reset_candidates', 'gpr_push_step', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
     'gpr_get_2D_rect_vertices', 'gpr_check_rectangles_intersect', 'gpr_ensure_max_dyn_val',
 )
 
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     lib.gpr_bind_state.argtypes = [vp, C.POINTER(GprState)]
     lib.gpr_seed.argtypes = [vp, u64]
     lib.gpr_reset.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
+    lib.gpr_reset_candidates.argtypes = [vp, vp, i32, vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_step_n.argtypes = [vp, i32, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_compute_reward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
@@ -103,6 +104,7 @@ def load() -> C.CDLL:
     lib.gpr_push_reset.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_push_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_push_reset_opts.argtypes = [vp, vp, vp, vp, C.POINTER(GprStepOut), vp]
+    lib.gpr_push_reset_candidates.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_qpos_is_valid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.gpr_check_mover_collision.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.gpr_check_line_segments_intersect.argtypes = [i64, vp, vp, vp, vp, vp, vp]

@@ -305,11 +305,13 @@ template <typename RT> void fill_push(const gpr_env &e, const gpr_push_params &p
     q.reach2 = (RT)(reach * reach);
 }
 
-int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, const void *opt_start = nullptr, const void *opt_goal = nullptr) {
+int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, const void *opt_start = nullptr, const void *opt_goal = nullptr,
+                int32_t n_cand = 0, const void *cand = nullptr, int32_t *cand_used = nullptr) {
     if (const int rc = check_device(env, is_reset ? "gpr_push_reset" : "gpr_push_step")) return rc;
     hipError_t he;
     PushPtrs X = env->push_ptrs;
     X.opt_start = opt_start; X.opt_goal = opt_goal;
+    X.cand = cand; X.cand_used = cand_used; X.n_cand = n_cand;
     switch (env->cfg.precision) {
         case GPR_PRECISION_F32:
             he = env->cfg.learn_jerk ? launch_push<float, double>(is_reset, P, env->push_d, X, s)
@@ -507,6 +509,21 @@ int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, vo
     return rc;
 }
 
+int gpr_reset_candidates(gpr_env *env, const uint8_t *mask_dev, int32_t n_cand, const void *cand_dev, int32_t *n_used_dev, const gpr_step_out *out,
+                         void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_reset_candidates: NULL handle");
+    if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_reset_candidates: call gpr_bind_state first");
+    if (n_cand < 2 || !cand_dev) return fail(env, GPR_E_INVALID, "gpr_reset_candidates: needs a stream of at least 2 candidate sets (one start set, one goal set)");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    KParams P = make_params(env, out, false);
+    P.mask = mask_dev;
+    P.cand = cand_dev; P.cand_used = n_used_dev; P.n_cand = n_cand;
+    rc = launch_env(env, true, P, as_stream(hip_stream));
+    if (rc == GPR_OK) env->tick += 1;
+    return rc;
+}
+
 int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_step: NULL handle");
     if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_step: call gpr_bind_state first");
@@ -626,7 +643,7 @@ int gpr_push_configure(gpr_env *env, const gpr_push_params *pp, const gpr_push_s
     if (!st->mover_rot_dev || !st->object_dev) return fail(env, GPR_E_INVALID, "gpr_push_configure: state pointers must be set");
     fill_push<float>(*env, *pp, env->push_f);
     fill_push<double>(*env, *pp, env->push_d);
-    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev, nullptr, nullptr};
+    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev, nullptr, nullptr, nullptr, nullptr, 0};
     env->push_ready = true;
     return GPR_OK;
 }
@@ -640,6 +657,20 @@ int gpr_push_reset_opts(gpr_env *env, const uint8_t *mask_dev, const void *mover
     KParams P = make_params(env, out, false);
     P.mask = mask_dev;
     rc = push_launch(env, true, P, as_stream(hip_stream), mover_start_xy_dev, object_goal_xy_dev);
+    if (rc == GPR_OK) env->tick += 1;
+    return rc;
+}
+
+int gpr_push_reset_candidates(gpr_env *env, const uint8_t *mask_dev, const void *mover_start_xy_dev, const void *object_goal_xy_dev, int32_t n_cand,
+                              const void *object_cand_dev, int32_t *n_used_dev, const gpr_step_out *out, void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_push_reset_candidates: NULL handle");
+    if (!env->bound || !env->push_ready) return fail(env, GPR_E_UNBOUND, "gpr_push_reset_candidates: call gpr_bind_state and gpr_push_configure first");
+    if (n_cand < 1 || !object_cand_dev) return fail(env, GPR_E_INVALID, "gpr_push_reset_candidates: needs at least one object candidate");
+    int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    KParams P = make_params(env, out, false);
+    P.mask = mask_dev;
+    rc = push_launch(env, true, P, as_stream(hip_stream), mover_start_xy_dev, object_goal_xy_dev, n_cand, object_cand_dev, n_used_dev);
     if (rc == GPR_OK) env->tick += 1;
     return rc;
 }

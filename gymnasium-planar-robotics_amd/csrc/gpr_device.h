@@ -53,6 +53,11 @@ struct KParams {
     int32_t *elapsed;
     const void *action;
     const uint8_t *mask;
+    // gpr_reset_candidates: a caller-supplied stream of candidate sets [n_cand][E][2M] (storage type) instead of the engine's own draws;
+    // the start loop consumes sets until it accepts one, the goal loop goes on from there (PL:369-413). cand_used [E] nullable.
+    const void *cand;
+    int32_t *cand_used;
+    int32_t n_cand;
     // outputs
     void *obs, *ag, *dg, *reward;
     uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
@@ -76,6 +81,9 @@ template <typename RT> struct PushCst {
 struct PushPtrs {
     void *mover_rot, *object;
     const void *opt_start, *opt_goal;   // reset options 'mover_start_xy_pos' [E][2 NM] / 'object_goal_xy_pos' [E][2] (PU:389-391, 412-414), nullable
+    const void *cand;                   // gpr_push_reset_candidates: the object's start candidates [n_cand][E][2] (PU:403-405), nullable
+    int32_t *cand_used;                 // [E] nullable: candidates consumed
+    int32_t n_cand;
 };
 template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
 template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }

@@ -64,7 +64,11 @@ __device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint3
 // group k of the set evaluates trial base + k, a ballot shows which are valid, the first one wins and its candidate is
 // fetched by ds_bpermute. S = 1 is the plain sequential loop (k_reset: one env per lane group). All S groups of a set
 // return the same p, g, flags and observation; the caller lets one of them store.
-template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE>
+// SCRIPT (k_reset only, S = 1): when P.cand is set the candidates come from the caller's stream [n_cand][E][2M] instead of the engine's
+// draws -- set k of the stream is the k-th sample np_random.uniform hands out: the start loop consumes sets until it accepts one, the
+// goal loop goes on from the next (the reference's two loops share one generator, PL:377 / PL:402). An exhausted stream ends a loop
+// like max_reset_trials does (the last set stands).
+template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE, bool SCRIPT = false>
 __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, bool live,
                                                bool need, RT c, RT c1, int S, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
     const Cst<RT> &C = cst<RT>(P);
@@ -84,10 +88,17 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     const int slot = gi & (S - 1), lead_lane = (gi & ~(S - 1)) * LPE;  // my trial offset in a round; first lane of my env's set
     const unsigned long long set_mask = S * LPE >= 64 ? ~0ull : ((1ull << (S * LPE)) - 1ull);
 
+    const bool scripted = SCRIPT && P.cand != nullptr;  // (wave-uniform)
+    int used = 0;                                        // scripted: sets of the stream this env has consumed so far
     auto candidate = [&](uint32_t key, int trial) {
         R2<RT> cn;
-        cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(key, 2u * (uint32_t)trial));  // PL:377 / PL:402
-        cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(key, 2u * (uint32_t)trial + 1u));
+        if (SCRIPT && scripted) {
+            const int k = used + trial < P.n_cand ? used + trial : P.n_cand - 1;
+            cn = load2<ST, RT>(P.cand, ((int64_t)k * P.E + (env_global - P.env_id_offset)) * (2 * (int64_t)M) + 2 * mvc);
+        } else {
+            cn.x = stored<ST, RT>(C.min_x + sx * rng_uniform<RT>(key, 2u * (uint32_t)trial));  // PL:377 / PL:402
+            cn.y = stored<ST, RT>(C.min_y + sy * rng_uniform<RT>(key, 2u * (uint32_t)trial + 1u));
+        }
         if (mv >= M) cn.x = cn.y = far_away<RT>();
         return cn;
     };
@@ -105,6 +116,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         const uint32_t key = pass == 0 ? ks : kg;
         bool pending = need;
         R2<RT> cand = pass == 0 ? p : g;
+        int taken = 0;  // scripted: sets this pass consumed
         for (int base = 0; base < P.max_reset_trials; base += S) {
             if (__ballot(pending) == 0ull) break;
             const int trial = base + slot;
@@ -126,7 +138,11 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
                 }
                 else hit = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);
             }
-            const bool bad = group_any<LPE>(w | hit);
+            bool bad = group_any<LPE>(w | hit);
+            if (SCRIPT && scripted) {  // (every lane went through the votes above; only the bookkeeping differs)
+                if (pending) taken = trial + 1;
+                if (used + trial >= P.n_cand - 1) bad = false;  // the stream's last set stands whatever it is
+            }
             if (S == 1) {  // (wave-uniform) the sequential form: the candidate stands as soon as it is valid, or as the last one
                 if (pending) { cand = cn; pending = bad; }
             } else {
@@ -139,6 +155,10 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         }
         if ((S != 1) & pending) cand = candidate(key, P.max_reset_trials - 1);  // trials exhausted: the last candidate stands
         if (need) { if (pass == 0) p = cand; else g = cand; }
+        used += taken;
+    }
+    if (SCRIPT && scripted) {
+        if ((P.cand_used != nullptr) & live & need & (mv == 0)) P.cand_used[env_global - P.env_id_offset] = used;
     }
 
     // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
@@ -1266,7 +1286,7 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
     if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
     bool wc, mc;
-    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, env_global, mv, mvc, live, need, c, c1, 1, p, g, wc, mc);
+    Obs<RT> o = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE, true>(P, T, env_global, mv, mvc, live, need, c, c1, 1, p, g, wc, mc);
     if (live & need) {
         const R2<RT> zero{(RT)0, (RT)0};
         store2<ST, RT>(P.pos, idx, p);

@@ -483,7 +483,14 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
     // the search is wave-cooperative: every lane tries its own first 8 trials; the lanes still looking are then served one
     // at a time, all 64 lanes testing 64 consecutive trials of that env, the first valid one in trial order wins -- the same
     // candidate the sequential loop accepts (the draws are indexed by trial). After max_reset_trials the last candidate stands.
-    auto candidate = [&](uint32_t key, int trial, RT &cx, RT &cy) {
+    // (X.cand: the caller's candidate stream [n_cand][E][2] instead of the engine's draws, gpr_push_reset_candidates; wave-uniform)
+    const int max_trials = X.cand != nullptr ? (X.n_cand < P.max_reset_trials ? X.n_cand : P.max_reset_trials) : P.max_reset_trials;
+    auto candidate = [&](uint32_t key, int64_t env, int trial, RT &cx, RT &cy) {
+        if (X.cand != nullptr) {
+            const R2<RT> cn = load2<ST, RT>(X.cand, ((int64_t)(trial < max_trials ? trial : max_trials - 1) * P.E + env) * 2);
+            cx = cn.x; cy = cn.y;
+            return;
+        }
         cx = stored<ST, RT>(Q.omin_x + (Q.omax_x - Q.omin_x) * rng_uniform<RT>(key, 2u + 2u * (uint32_t)trial));
         cy = stored<ST, RT>(Q.omin_y + (Q.omax_y - Q.omin_y) * rng_uniform<RT>(key, 3u + 2u * (uint32_t)trial));
     };
@@ -495,30 +502,33 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
     };
     constexpr int NSELF = 8;
     bool pending = need;
-    for (int trial = 0; trial < NSELF && trial < P.max_reset_trials; ++trial) {
+    int n_tried = 0;
+    for (int trial = 0; trial < NSELF && trial < max_trials; ++trial) {
         if (__ballot(pending) == 0ull) break;
         RT cx, cy;
-        candidate(ks[0], trial, cx, cy);
-        if (pending) { ox = cx; oy = cy; pending = !far_enough(cx, cy, p); }
+        candidate(ks[0], e, trial, cx, cy);
+        if (pending) { ox = cx; oy = cy; pending = !far_enough(cx, cy, p); n_tried = trial + 1; }
     }
     for (unsigned long long pm = __ballot(pending); pm != 0ull; pm &= pm - 1ull) {
         const int L = __builtin_ctzll(pm);
         const uint32_t ksL = (uint32_t)__builtin_amdgcn_readlane((int)ks[0], L);
+        const int64_t eL = ((int64_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, L);
         R2<RT> mp[NM];
 #pragma unroll
         for (int i = 0; i < NM; ++i) { mp[i].x = lane_bcast<RT>(p[i].x, L); mp[i].y = lane_bcast<RT>(p[i].y, L); }
-        int found = P.max_reset_trials - 1;
-        for (int base = NSELF; base < P.max_reset_trials; base += 64) {
+        int found = max_trials - 1;
+        for (int base = NSELF; base < max_trials; base += 64) {
             const int trial = base + (int)__lane_id();
             RT cx, cy;
-            candidate(ksL, trial, cx, cy);
-            const unsigned long long okm = __ballot((trial < P.max_reset_trials) & far_enough(cx, cy, mp));
+            candidate(ksL, eL, trial, cx, cy);
+            const unsigned long long okm = __ballot((trial < max_trials) & far_enough(cx, cy, mp));
             if (okm != 0ull) { found = base + __builtin_ctzll(okm); break; }
         }
         RT cx, cy;
-        candidate(ksL, found, cx, cy);
-        if ((int)__lane_id() == L) { ox = cx; oy = cy; }
+        candidate(ksL, eL, found, cx, cy);
+        if ((int)__lane_id() == L) { ox = cx; oy = cy; n_tried = found + 1; }
     }
+    if ((X.cand != nullptr) & (X.cand_used != nullptr) & need) X.cand_used[e] = n_tried;
     if (X.opt_goal != nullptr) {
         g = load2<ST, RT>(X.opt_goal, 2 * e);  // PU:412-414
     } else {

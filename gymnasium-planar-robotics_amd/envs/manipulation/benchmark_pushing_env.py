@@ -167,7 +167,8 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         """PU:373-417 + BE:1770-1833. ``options``: ``'mask'`` (bool tensor) resets a subset; the reference's
         ``'mover_start_xy_pos'`` ((num_movers, 2), or batched (num_envs, num_movers, 2)) fixes the mover start(s) -- the object's start
         is still rejection-sampled to keep ``min_mo_dist`` from it (PU:396-407) -- and ``'object_goal_xy_pos'`` ((2,) or
-        (num_envs, 2)) fixes the goal (PU:389-391, 412-414)."""
+        (num_envs, 2)) fixes the goal (PU:389-391, 412-414). Engine option ``'object_candidates'`` ((n_cand, num_envs, 2)): the object's start
+        candidates of PU:403-405 from the caller instead of the engine's draws, tried in order (``info['candidates_used']``)."""
         if seed is not None or self._needs_seed:
             _native.check(self._lib.gpr_seed(self._handle, int(seed if seed is not None else np.random.SeedSequence().entropy % (1 << 63))),
                           self._handle)
@@ -186,6 +187,15 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
             return t.expand(self.num_envs, width).contiguous()
 
         start, goal = fixed('mover_start_xy_pos', 2 * self.num_movers), fixed('object_goal_xy_pos', 2)
+        if options.get('object_candidates') is not None:
+            cand = torch.as_tensor(options['object_candidates'], device=self.device).to(self.dtype).reshape(-1, self.num_envs, 2).contiguous()
+            used = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(self._lib.gpr_push_reset_candidates(self._handle, mask.data_ptr() if mask is not None else None,
+                                                                  start.data_ptr() if start is not None else None,
+                                                                  goal.data_ptr() if goal is not None else None, cand.shape[0], cand.data_ptr(),
+                                                                  used.data_ptr(), C.byref(self._out), self._stream()), self._handle)
+            return OrderedDict(self._obs), dict(self._info_dict(), candidates_used=used)
         with torch.cuda.device(self.device):
             _native.check(self._lib.gpr_push_reset_opts(self._handle, mask.data_ptr() if mask is not None else None,
                                                         start.data_ptr() if start is not None else None,

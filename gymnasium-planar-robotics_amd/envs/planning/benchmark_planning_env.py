@@ -179,7 +179,12 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
 
     def reset(self, seed: int | None = None, options: dict[str, Any] | None = None) -> tuple[OrderedDict, dict[str, torch.Tensor]]:
         """Reset envs (BE:1770-1833 + PL:355-418): rejection-sample collision-free starts and valid goals, zero the velocities,
-        return the initial observation and info. ``options={'mask': bool tensor (num_envs,)}`` resets a subset."""
+        return the initial observation and info. ``options={'mask': bool tensor (num_envs,)}`` resets a subset.
+
+        ``options={'candidates': tensor (n_cand, num_envs, num_movers, 2)}`` puts the generator of PL:377 / PL:402 into the caller's
+        hands (scripted / curriculum resets): set ``k`` is the ``k``-th sample ``np_random.uniform`` would hand out -- per env the start
+        loop consumes sets until one passes its checks, the goal loop goes on from the next one, and a loop that reaches the end of the
+        stream keeps the last set. ``info['candidates_used']`` (int32, (num_envs,)) tells how many sets each env consumed."""
         if seed is not None or self._needs_seed:
             _native.check(self._lib.gpr_seed(self._handle, int(seed if seed is not None else np.random.SeedSequence().entropy % (1 << 63))),
                           self._handle)
@@ -188,6 +193,15 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         if options is not None and options.get('mask') is not None:
             mask = torch.as_tensor(options['mask'], device=self.device).to(torch.uint8).contiguous()
             assert mask.shape == (self.num_envs,)
+        cand = options.get('candidates') if options is not None else None
+        if cand is not None:
+            cand = torch.as_tensor(cand, device=self.device).to(self.dtype).reshape(-1, self.num_envs, 2 * self.num_movers).contiguous()
+            assert cand.shape[0] >= 2, 'the candidate stream needs at least one start set and one goal set'
+            used = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(self._lib.gpr_reset_candidates(self._handle, mask.data_ptr() if mask is not None else None, cand.shape[0],
+                                                             cand.data_ptr(), used.data_ptr(), C.byref(self._out), self._stream()), self._handle)
+            return self._obs_dict(), dict(self._info_dict(), candidates_used=used)
         with torch.cuda.device(self.device):
             _native.check(self._lib.gpr_reset(self._handle, mask.data_ptr() if mask is not None else None, C.byref(self._out),
                                               self._stream()), self._handle)

@@ -115,6 +115,14 @@ int gpr_set_rng_state(gpr_env *env, uint64_t seed, uint64_t tick);
 /* reset() (BE:1770-1833 + PL:355-418). mask_dev: nullable [E] bytes, non-zero = reset this env. Fills `out`
  * (reward 0, terminated/truncated 0) for the envs it resets. */
 int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream);
+/* reset() on a caller-supplied stream of candidate sets instead of the engine's own draws -- the reference's
+ * `self.np_random.uniform(low=self.min_xy_pos, high=self.max_xy_pos, size=(num_movers, 2))` (PL:377, PL:402) with the generator in the
+ * caller's hands (scripted / curriculum resets; and how tests/golden/reset_template.npz -- reset() and _reset_callback called as written
+ * on a scripted generator -- is checked). cand_dev [n_cand][E][2M] real: set k is the k-th sample the generator hands out. Per env the
+ * start loop (PL:369-385) consumes sets until one passes its checks, the goal loop (PL:395-413) goes on from the next one; a loop that
+ * reaches the stream's end keeps the last set (as max_reset_trials does). n_used_dev [E] int32, nullable: sets consumed per env. */
+int gpr_reset_candidates(gpr_env *env, const uint8_t *mask_dev, int32_t n_cand, const void *cand_dev, int32_t *n_used_dev,
+                         const gpr_step_out *out, void *hip_stream);
 /* step(action) (BE:1835-1950 + PL:420-450 + TimeLimit). action_dev: [E][2M] real, clipped to the action space. */
 int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
 
@@ -205,6 +213,11 @@ int gpr_push_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *ou
  * start is still rejection-sampled against min_mo_dist from the given mover position(s), as PU:396-407 does. */
 int gpr_push_reset_opts(gpr_env *env, const uint8_t *mask_dev, const void *mover_start_xy_dev, const void *object_goal_xy_dev,
                         const gpr_step_out *out, void *hip_stream);
+/* ... and with the object's start candidates (PU:403-405: `np_random.uniform(object_min_xy_pos, object_max_xy_pos)` inside the rejection
+ * loop) from the caller: object_cand_dev [n_cand][E][2] real, tried in order until one is farther than min_mo_dist from every mover
+ * (PU:407), the last one standing otherwise; n_used_dev [E] int32 nullable. */
+int gpr_push_reset_candidates(gpr_env *env, const uint8_t *mask_dev, const void *mover_start_xy_dev, const void *object_goal_xy_dev,
+                              int32_t n_cand, const void *object_cand_dev, int32_t *n_used_dev, const gpr_step_out *out, void *hip_stream);
 int gpr_push_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
 
 /* ---- stateless operators (f64, device pointers) --------------------------------------------------------------- */

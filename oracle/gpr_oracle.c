@@ -583,8 +583,21 @@ static void observe(const env_ctx *c, const uint32_t *keys, uint32_t q0, const d
 }
 
 /* _reset_callback (PL:355-418) + reset() (BE:1770-1833) for one env; leaves the reset observation in out. */
+/* A scripted candidate stream (gpro_planning_reset_candidates): what np_random.uniform hands out, in order -- the start loop consumes
+ * sets from it until it accepts, the goal loop goes on from there (the two loops share ONE generator, PL:377 / PL:402). NULL: the
+ * engine's own counter-based draws. */
+typedef struct { const double *cand; int64_t stride; int32_t n; int32_t *n_used; } cand_stream;
+
+static void reset_one_from(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t env_id, int64_t e, double *pos, double *vel, double *acc,
+                           double *goal, int32_t *elapsed, gpro_step_out *out, double *margin, const cand_stream *cs);
+
 static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t env_id, int64_t e, double *pos, double *vel, double *acc,
                       double *goal, int32_t *elapsed, gpro_step_out *out, double *margin) {
+    reset_one_from(c, seed, tick, env_id, e, pos, vel, acc, goal, elapsed, out, margin, NULL);
+}
+
+static void reset_one_from(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t env_id, int64_t e, double *pos, double *vel, double *acc,
+                           double *goal, int32_t *elapsed, gpro_step_out *out, double *margin, const cand_stream *cs) {
     const gpro_env_cfg *cfg = c->cfg;
     int M = cfg->num_movers;
     uint32_t ks[GPRO_MAX_MOVERS], kg[GPRO_MAX_MOVERS], kn[GPRO_MAX_MOVERS];
@@ -594,12 +607,16 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
         kn[i] = gpro_rng_key(seed, tick, KIND_RESET_NOISE, (uint64_t)env_id, (uint32_t)i);
     }
     double xy[GPRO_MAX_MOVERS * 2];
-    for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PL:369-385 */
+    int used = 0; /* sets taken from the scripted stream so far */
+    const int trials0 = cs ? (cs->n < cfg->max_reset_trials ? cs->n : cfg->max_reset_trials) : cfg->max_reset_trials;
+    for (int trial = 0; trial < trials0; ++trial) { /* PL:369-385 */
         for (int k = 0; k < 2 * M; ++k) {
             int d = k & 1;
+            if (cs) { xy[k] = q32(cfg, cs->cand[(int64_t)trial * cs->stride + k]); continue; }
             double u = gpro_rng_uniform(ks[k >> 1], 2u * (uint32_t)trial + (uint32_t)d);
             xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:377 */
         }
+        used = trial + 1;
         double qp[GPRO_MAX_MOVERS * 7];
         noisy_qpos(c, ks, 0, M, xy, 0.0, 0, qp);
         int wall = wall_any(c, qp, 1, margin);  /* PL:379 add_safety_offset=True */
@@ -607,12 +624,16 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
         if (!coll && !wall) break;
     }
     memcpy(pos, xy, sizeof(double) * 2 * M);
-    for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PL:395-413 */
+    const int used0 = used;
+    const int trials1 = cs ? (cs->n - used0 < cfg->max_reset_trials ? cs->n - used0 : cfg->max_reset_trials) : cfg->max_reset_trials;
+    for (int trial = 0; trial < trials1; ++trial) { /* PL:395-413 */
         for (int k = 0; k < 2 * M; ++k) {
             int d = k & 1;
+            if (cs) { xy[k] = q32(cfg, cs->cand[(int64_t)(used0 + trial) * cs->stride + k]); continue; }
             double u = gpro_rng_uniform(kg[k >> 1], 2u * (uint32_t)trial + (uint32_t)d);
             xy[k] = q32(cfg, cfg->min_xy[d] + (cfg->max_xy[d] - cfg->min_xy[d]) * u); /* PL:402 */
         }
+        used = used0 + trial + 1;
         double qp[GPRO_MAX_MOVERS * 7];
         noisy_qpos(c, kg, 0, M, xy, 0.0, 0, qp);
         int wall = wall_any(c, qp, 1, margin); /* PL:403-404 */
@@ -628,6 +649,7 @@ static void reset_one(const env_ctx *c, uint64_t seed, uint64_t tick, int64_t en
         if (ok) break;
     }
     memcpy(goal, xy, sizeof(double) * 2 * M);
+    if (cs && cs->n_used) *cs->n_used = used;
     for (int k = 0; k < 2 * M; ++k) { vel[k] = 0.0; acc[k] = 0.0; } /* reload_model + mj_forward: v = 0, act = 0, qacc = 0 */
     *elapsed = 0;
     double qp[GPRO_MAX_MOVERS * 7];
@@ -659,6 +681,28 @@ int32_t gpro_planning_reset(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t 
         double m = INFINITY;
         reset_one(&c, seed, tick, env_id_offset + e, e, pos + 2 * M * e, vel + 2 * M * e, acc + 2 * M * e, goal + 2 * M * e, elapsed + e,
                   out, out->margin ? &m : NULL);
+        out->reward[e] = 0.0;
+        out->terminated[e] = 0;
+        if (out->margin) out->margin[e] = m;
+    }
+    return 0;
+}
+
+/* reset() with np_random.uniform scripted: cand [n_cand][E][2M] is the stream of candidate sets of every env, n_used [E] (nullable)
+ * receives how many sets the env's two loops consumed. An exhausted stream ends a loop like max_reset_trials does (the last set stands). */
+int32_t gpro_planning_reset_candidates(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset,
+                                       const uint8_t *mask, int32_t n_cand, const double *cand, int32_t *n_used, double *pos, double *vel,
+                                       double *acc, double *goal, int32_t *elapsed, gpro_step_out *out) {
+    if (cfg->num_movers < 1 || cfg->num_movers > GPRO_MAX_MOVERS || n_cand < 2 || !cand) return -1;
+    env_ctx c;
+    ctx_init(&c, cfg);
+    int M = cfg->num_movers;
+    for (int64_t e = 0; e < num_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        double m = INFINITY;
+        cand_stream cs = {cand + 2 * M * e, 2 * (int64_t)M * num_envs, n_cand, n_used ? n_used + e : NULL};
+        reset_one_from(&c, seed, tick, env_id_offset + e, e, pos + 2 * M * e, vel + 2 * M * e, acc + 2 * M * e, goal + 2 * M * e, elapsed + e,
+                       out, out->margin ? &m : NULL, &cs);
         out->reward[e] = 0.0;
         out->terminated[e] = 0;
         if (out->margin) out->margin[e] = m;
@@ -974,7 +1018,7 @@ static void push_observe(const env_ctx *c, const gpro_push_params *pp, const uin
  * sampled). 2 movers: their starts are re-drawn together until the two collision circles (with the safety offset) are apart. */
 static void push_reset_one(const env_ctx *c, const gpro_push_params *pp, uint64_t seed, uint64_t tick, int64_t env_id, int64_t e, double *pos,
                            double *vel, double *acc, double *rot, double *object, double *goal, int32_t *elapsed, const double *opt_start,
-                           const double *opt_goal, gpro_step_out *out, double *margin) {
+                           const double *opt_goal, gpro_step_out *out, double *margin, const cand_stream *cs) {
     const gpro_env_cfg *cfg = c->cfg;
     const int nm = cfg->num_movers;
     uint32_t ks[2], kr[2], kn[2];
@@ -999,9 +1043,12 @@ static void push_reset_one(const env_ctx *c, const gpro_push_params *pp, uint64_
             if (!pair_any(c, qp, 1, margin)) break;
         }
     }
-    for (int trial = 0; trial < cfg->max_reset_trials; ++trial) { /* PU:396-407 */
+    const int otrials = cs ? (cs->n < cfg->max_reset_trials ? cs->n : cfg->max_reset_trials) : cfg->max_reset_trials;
+    for (int trial = 0; trial < otrials; ++trial) { /* PU:396-407 */
         for (int d = 0; d < 2; ++d)
-            object[d] = q32(cfg, pp->obj_min_xy[d] + (pp->obj_max_xy[d] - pp->obj_min_xy[d]) * gpro_rng_uniform(ks[0], 2u + 2u * (uint32_t)trial + (uint32_t)d));
+            object[d] = cs ? q32(cfg, cs->cand[(int64_t)trial * cs->stride + d])
+                           : q32(cfg, pp->obj_min_xy[d] + (pp->obj_max_xy[d] - pp->obj_min_xy[d]) * gpro_rng_uniform(ks[0], 2u + 2u * (uint32_t)trial + (uint32_t)d));
+        if (cs && cs->n_used) *cs->n_used = trial + 1;
         int ok = 1;
         for (int i = 0; i < nm; ++i) {
             double dx = object[0] - pos[2 * i], dy = object[1] - pos[2 * i + 1], dist = sqrt(dx * dx + dy * dy);
@@ -1036,7 +1083,29 @@ int32_t gpro_pushing_reset(const gpro_env_cfg *cfg, const gpro_push_params *pp, 
         double m = INFINITY;
         push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos + 2 * nm * e, vel + 2 * nm * e, acc + 2 * nm * e, mover_rot + 2 * nm * e,
                        object + 6 * e, goal + 2 * e, elapsed + e, opt_mover_start ? opt_mover_start + 2 * nm * e : NULL,
-                       opt_goal ? opt_goal + 2 * e : NULL, out, out->margin ? &m : NULL);
+                       opt_goal ? opt_goal + 2 * e : NULL, out, out->margin ? &m : NULL, NULL);
+        out->reward[e] = 0.0; out->terminated[e] = 0;
+        if (out->margin) out->margin[e] = m;
+    }
+    return 0;
+}
+
+/* gpro_pushing_reset with the object's start candidates scripted (PU:403-405): cand [n_cand][E][2], n_used [E] nullable */
+int32_t gpro_pushing_reset_candidates(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
+                                      int64_t env_id_offset, const uint8_t *mask, const double *opt_mover_start, const double *opt_goal,
+                                      int32_t n_cand, const double *cand, int32_t *n_used, double *pos, double *vel, double *acc,
+                                      double *mover_rot, double *object, double *goal, int32_t *elapsed, gpro_step_out *out) {
+    const int nm = cfg->num_movers;
+    if (nm < 1 || nm > 2 || n_cand < 1 || !cand) return -1;
+    env_ctx c;
+    ctx_init(&c, cfg);
+    for (int64_t e = 0; e < num_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        double m = INFINITY;
+        cand_stream cs = {cand + 2 * e, 2 * num_envs, n_cand, n_used ? n_used + e : NULL};
+        push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos + 2 * nm * e, vel + 2 * nm * e, acc + 2 * nm * e, mover_rot + 2 * nm * e,
+                       object + 6 * e, goal + 2 * e, elapsed + e, opt_mover_start ? opt_mover_start + 2 * nm * e : NULL,
+                       opt_goal ? opt_goal + 2 * e : NULL, out, out->margin ? &m : NULL, &cs);
         out->reward[e] = 0.0; out->terminated[e] = 0;
         if (out->margin) out->margin[e] = m;
     }
@@ -1058,7 +1127,7 @@ int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, i
         double mg = INFINITY;
         double *margin = out->margin ? &mg : NULL;
         if (autoreset == 2 && elapsed_a[e] < 0) {
-            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, NULL, NULL, out, margin);
+            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, NULL, NULL, out, margin, NULL);
             out->reward[e] = 0.0; out->terminated[e] = 0;
             if (out->margin) out->margin[e] = mg;
             continue;
@@ -1116,7 +1185,7 @@ int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, i
             if (out->final_desired_goal) memcpy(out->final_desired_goal + 2 * e, out->desired_goal + 2 * e, sizeof(double) * 2);
             double r = out->reward[e];
             uint8_t t = out->terminated[e], s = out->is_success[e], pw = out->wall_collision[e], pm = out->mover_collision[e];
-            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, NULL, NULL, out, margin);
+            push_reset_one(&c, pp, seed, tick, env_id_offset + e, e, pos, vel, acc, rot, obj, goal, elapsed_a + e, NULL, NULL, out, margin, NULL);
             out->reward[e] = r; out->terminated[e] = t; out->truncated[e] = (uint8_t)trunc; out->is_success[e] = s; out->wall_collision[e] = pw;
             out->mover_collision[e] = pm;
         } else if (done && autoreset == 2) {

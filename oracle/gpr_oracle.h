@@ -119,6 +119,12 @@ typedef struct {
 int32_t gpro_planning_reset(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick,
                             int64_t env_id_offset, const uint8_t *mask, double *pos, double *vel, double *acc,
                             double *goal, int32_t *elapsed, gpro_step_out *out);
+/* reset() with np_random.uniform SCRIPTED (tests/golden/reset_template.npz: the reference's reset() / _reset_callback called as written
+ * on such a stream): cand [n_cand][E][2M] = the candidate sets in the order the generator hands them out; the start loop consumes
+ * sets until it accepts one, the goal loop goes on from there (PL:369-413). n_used [E] (nullable): sets consumed per env. */
+int32_t gpro_planning_reset_candidates(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset,
+                                       const uint8_t *mask, int32_t n_cand, const double *cand, int32_t *n_used, double *pos, double *vel,
+                                       double *acc, double *goal, int32_t *elapsed, gpro_step_out *out);
 int32_t gpro_planning_step(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick,
                            int64_t env_id_offset, const double *action, double *pos, double *vel, double *acc,
                            double *goal, int32_t *elapsed, int32_t autoreset, gpro_step_out *out);
@@ -166,6 +172,11 @@ typedef struct {
 int32_t gpro_pushing_reset(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
                            int64_t env_id_offset, const uint8_t *mask, const double *opt_mover_start, const double *opt_goal, double *pos,
                            double *vel, double *acc, double *mover_rot, double *object, double *goal, int32_t *elapsed, gpro_step_out *out);
+/* the same with the object's start candidates scripted (PU:403-405): cand [n_cand][E][2], n_used [E] nullable */
+int32_t gpro_pushing_reset_candidates(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
+                                      int64_t env_id_offset, const uint8_t *mask, const double *opt_mover_start, const double *opt_goal,
+                                      int32_t n_cand, const double *cand, int32_t *n_used, double *pos, double *vel, double *acc,
+                                      double *mover_rot, double *object, double *goal, int32_t *elapsed, gpro_step_out *out);
 int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, int64_t num_envs, uint64_t seed, uint64_t tick,
                           int64_t env_id_offset, const double *action, double *pos, double *vel, double *acc, double *mover_rot,
                           double *object, double *goal, int32_t *elapsed, int32_t autoreset, gpro_step_out *out);

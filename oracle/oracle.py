@@ -244,6 +244,18 @@ class OraclePlanningEnv:
         self.tick += 1
         return self._result()
 
+    def reset_candidates(self, cand, mask=None):
+        """reset() on a scripted candidate stream: cand [n_cand, E, M, 2] (or [n_cand, E, 2M]); -> (result, sets consumed per env)"""
+        cand = np.ascontiguousarray(np.asarray(cand, dtype=np.float64).reshape(-1, self.E, 2 * self.M))
+        n_used = np.zeros(self.E, dtype=np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        rc = lib().gpro_planning_reset_candidates(C.byref(self.cfg), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick),
+                                                  C.c_int64(self.env_id_offset), _p(m), C.c_int32(cand.shape[0]), _p(cand), _p(n_used),
+                                                  _p(self.pos), _p(self.vel), _p(self.acc), _p(self.goal), _p(self.elapsed), C.byref(self.out))
+        assert rc == 0
+        self.tick += 1
+        return self._result(), n_used
+
     def step(self, action):
         a = _f64(action).reshape(self.E, 2 * self.M)
         args = [C.byref(self.cfg), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick), C.c_int64(self.env_id_offset), _p(a),
@@ -317,6 +329,21 @@ class OraclePushingEnv:
         assert rc == 0
         self.tick += 1
         return self._result()
+
+    def reset_candidates(self, object_cand, mask=None, mover_start_xy_pos=None, object_goal_xy_pos=None):
+        """reset() with the object's start candidates scripted: object_cand [n_cand, E, 2]; -> (result, candidates consumed per env)"""
+        cand = np.ascontiguousarray(np.asarray(object_cand, dtype=np.float64).reshape(-1, self.E, 2))
+        n_used = np.zeros(self.E, dtype=np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        ms = None if mover_start_xy_pos is None else np.ascontiguousarray(np.broadcast_to(np.asarray(mover_start_xy_pos, dtype=np.float64).reshape(-1, 2 * self.NM), (self.E, 2 * self.NM)))
+        og = None if object_goal_xy_pos is None else np.ascontiguousarray(np.broadcast_to(np.asarray(object_goal_xy_pos, dtype=np.float64).reshape(-1, 2), (self.E, 2)))
+        rc = lib().gpro_pushing_reset_candidates(C.byref(self.cfg), C.byref(self.pp), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick),
+                                                 C.c_int64(self.env_id_offset), _p(m), _p(ms), _p(og), C.c_int32(cand.shape[0]), _p(cand), _p(n_used),
+                                                 _p(self.pos), _p(self.vel), _p(self.acc), _p(self.rot), _p(self.object), _p(self.goal),
+                                                 _p(self.elapsed), C.byref(self.out))
+        assert rc == 0
+        self.tick += 1
+        return self._result(), n_used
 
     def step(self, action):
         a = _f64(action).reshape(self.E, 2 * self.NM)

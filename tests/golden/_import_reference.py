@@ -41,6 +41,15 @@ class _DummyModel:
     def from_xml_string(cls, xml: str) -> '_DummyModel':
         return cls(xml)
 
+    # name -> id lookups made by MoverImpedanceController.__init__ (utils/impedance_control.py:37-46) when BenchmarkPushingEnv is
+    # constructed: plain indices. The mass only enters the controller's damping matrix, which no fixture evaluates
+    # (its update() needs mj_jacBody and is never called here).
+    def joint(self, name):
+        return types.SimpleNamespace(bodyid=[0])
+
+    def body(self, idx):
+        return types.SimpleNamespace(dofadr=[0], dofnum=[6], mass=[1.0])
+
 
 class _DummyData:
     def __init__(self, model: _DummyModel) -> None:

@@ -25,6 +25,16 @@ known-answer cases the reference's own tests hold):
                                  velocities / accelerations / actions -> the ctrl values it hands to MuJoCo (acc and jerk mode,
                                  incl. the "velocity clamp overrides the jerk" branch PL:437-440)
 
+  step_template.npz              BasicPlanarRoboticsSingleAgentEnv.step (BE:1835-1950) called AS WRITTEN on BenchmarkPlanningEnv objects, sigma = 0,
+                                 with the MuJoCo calls replaced by a stand-in "world" (see World below): pins the TEMPLATE's control flow --
+                                 clip, the cycle loop with its break, the flags / state / observation of the colliding cycle, reward,
+                                 terminated, info -- NOT mj_step itself (a4: that is trajectories.npz)
+  reset_template.npz             BasicPlanarRoboticsSingleAgentEnv.reset (BE:1770-1833) + BenchmarkPlanningEnv._reset_callback (PL:355-418) called
+                                 AS WRITTEN with np_random.uniform scripted to hand out a prescribed candidate sequence: "the first valid
+                                 set in order wins; starts, then goals; goals are not checked against starts" (row a14)
+  pushing_methods.npz            BenchmarkPushingEnv._get_obs (PU:529-576), compute_reward / compute_terminated (PU:457-527) on arrays of info
+                                 dicts, _reset_callback (PU:373-417) incl. the `options`, with scripted np_random.uniform -- as written (a16)
+
 MuJoCo itself is not installed, so nothing here depends on mj_step (see _import_reference.py).
 """
 from __future__ import annotations
@@ -590,7 +600,397 @@ def gen_step_callback(seed=41, n=400):
     np.savez_compressed(os.path.join(HERE, 'step_callback.npz'), **out)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 10. the step() / reset() TEMPLATES as written, on a stand-in world (round 3)
+# ----------------------------------------------------------------------------------------------------------
+class World:
+    """What the reference's methods see instead of MuJoCo's model / data while the template fixtures are taken.
+
+    It holds the free-joint state of M movers (+ optionally one object) and answers exactly the calls the methods under test make:
+    mujoco_utils.get_joint_qpos / qvel / qacc, mujoco_utils.set_actuator_ctrl, mujoco.mj_step, mujoco.mj_forward. Its mj_step is the
+    closed form the reference's own tests assert MuJoCo equals for this MJCF (tests/test_benchmark_planning_env.py:86-121,199-231):
+    qacc = ctrl (jerk mode: act += dt * ctrl, qacc = act), v += dt * qacc, p += dt * v. It is a STUB: it pins which calls the
+    templates make in which order and what they do with the answers (rows a1 / a14), not MuJoCo's integrator (row a4)."""
+
+    def __init__(self, env, jerk):
+        self.env, self.jerk, self.M = env, jerk, env.num_movers
+        self.dt = 0.001
+        self.load(np.zeros((self.M, 2)))
+        self.object_qpos = np.array([0.12, 0.36, 0.02, 1.0, 0.0, 0.0, 0.0])
+
+    def load(self, start_xy):  # what compiling the MJCF of reload_model yields: bodies at their start poses, at rest (BE:1069)
+        M = self.M
+        self.qpos = np.zeros((M, 7)); self.qvel = np.zeros((M, 6)); self.qacc = np.zeros((M, 6)); self.act = np.zeros((M, 2))
+        self.qpos[:, :2] = np.asarray(start_xy, dtype=np.float64).reshape(M, 2)
+        self.qpos[:, 2] = self.env.initial_mover_zpos + self.env.mover_size[:, 2]
+        self.qpos[:, 3] = 1.0
+        self.ctrl = {}
+
+    def _idx(self, joint_name):
+        return self.env.mover_joint_names.index(joint_name)
+
+    def install(self):
+        import mujoco
+        from gymnasium_planar_robotics.utils import mujoco_utils
+        self._saved = (mujoco_utils.get_joint_qpos, mujoco_utils.get_joint_qvel, mujoco_utils.get_joint_qacc, mujoco_utils.set_actuator_ctrl,
+                       mujoco.mj_step, mujoco.mj_forward)
+        obj = getattr(self.env, 'object_joint_name', None)
+        mujoco_utils.get_joint_qpos = lambda model, data, name: (self.object_qpos.copy() if name == obj else self.qpos[self._idx(name)].copy())
+        mujoco_utils.get_joint_qvel = lambda model, data, name: self.qvel[self._idx(name)].copy()
+        mujoco_utils.get_joint_qacc = lambda model, data, name: self.qacc[self._idx(name)].copy()
+        mujoco_utils.set_actuator_ctrl = lambda model, data, actuator_name, value: self.ctrl.__setitem__(actuator_name, float(value))
+        mujoco.mj_step = lambda model, data, nstep=1: self.mj_step()
+        mujoco.mj_forward = lambda model, data: None
+        orig_reload = self.env.reload_model
+
+        def reload_and_load(mover_start_xy_pos=None, mover_goal_xy_pos=None, **kw):
+            if mover_goal_xy_pos is None:
+                orig_reload(mover_start_xy_pos=mover_start_xy_pos, **kw)
+            else:
+                orig_reload(mover_start_xy_pos=mover_start_xy_pos, mover_goal_xy_pos=mover_goal_xy_pos, **kw)
+            self.load(mover_start_xy_pos)
+
+        self.env.reload_model = reload_and_load
+        return self
+
+    def uninstall(self):
+        import mujoco
+        from gymnasium_planar_robotics.utils import mujoco_utils
+        (mujoco_utils.get_joint_qpos, mujoco_utils.get_joint_qvel, mujoco_utils.get_joint_qacc, mujoco_utils.set_actuator_ctrl, mujoco.mj_step,
+         mujoco.mj_forward) = self._saved
+
+    def mj_step(self):
+        dt, env = self.dt, self.env
+        for i in range(self.M):
+            u = np.array([self.ctrl[env.mover_actuator_x_names[i]], self.ctrl[env.mover_actuator_y_names[i]]])
+            if self.jerk:
+                self.act[i] = self.act[i] + dt * u
+                qacc = self.act[i].copy()
+            else:
+                qacc = u
+            self.qacc[i, :2] = qacc
+            self.qvel[i, :2] = self.qvel[i, :2] + dt * qacc
+            self.qpos[i, :2] = self.qpos[i, :2] + dt * self.qvel[i, :2]
+
+
+def reference_valid_sets(env, world, seed0):
+    """(starts, goals) accepted by the reference's own unscripted _reset_callback. On layouts with holes qpos_is_valid can trip its own
+    sanity assertion (BE:650, mask_valid > 1 for some positions near two missing tiles): such seeds are skipped."""
+    for r in range(seed0, seed0 + 1000):
+        env.np_random = np.random.default_rng(r)
+        try:
+            BenchmarkPlanningEnv._reset_callback(env, None)
+        except AssertionError:
+            continue
+        return world.qpos[:, :2].copy(), env.goals.copy()
+    raise RuntimeError('no assertion-free reset found')
+
+
+def reference_accepts_without_assert(env, xy):
+    q = np.zeros((env.num_movers, 7)); q[:, 2] = env.initial_mover_zpos; q[:, 3] = 1; q[:, :2] = xy
+    try:
+        env.qpos_is_valid(qpos=q, c_size=env.c_size, add_safety_offset=True)
+        return True
+    except AssertionError:
+        return False
+
+
+class ScriptedUniform:
+    """np_random stand-in whose uniform() hands out a prescribed sequence of samples and remembers how it was asked"""
+
+    def __init__(self, samples):
+        self.samples, self.calls = [np.asarray(x, dtype=np.float64) for x in samples], []
+
+    def uniform(self, low, high, size=None):
+        self.calls.append((np.array(low, dtype=np.float64), np.array(high, dtype=np.float64), tuple(np.atleast_1d(size))))
+        x = self.samples[len(self.calls) - 1]
+        assert x.shape == tuple(np.atleast_1d(size)), (x.shape, size)
+        return x.copy()
+
+
+STEP_TEMPLATE_CONFIGS = [
+    # tag, layout, M, jerk, collision_params, num_cycles
+    ('acc_M1', np.ones((3, 3)), 1, False, {}, 40),
+    ('acc_M2', np.ones((4, 4)), 2, False, {}, 40),
+    ('acc_M4', np.ones((6, 6)), 4, False, {}, 40),
+    ('jerk_M2', np.ones((4, 4)), 2, True, {}, 40),
+    ('acc_M3_holes', np.array([[1, 1, 1, 1], [1, 1, 0, 1], [1, 1, 1, 1], [1, 0, 1, 1]]), 3, False, {'offset': 0.01, 'offset_wall': 0.002}, 25),
+    ('acc_M2_box', np.ones((4, 4)), 2, False, {'shape': 'box', 'size': np.array([0.0775, 0.0775])}, 40),
+]
+
+
+def gen_step_template(seed=51, E=48, T=6):
+    """E scenarios x T consecutive step() calls per configuration. Scenarios are built so that every exit of the template is taken:
+    a wall collision in some cycle k (start near a wall, moving towards it), a mover collision in some cycle (two movers on a
+    collision course), all goals reached (+50), some reached (-(M - n)), none, and actions outside the action space (clipped)."""
+    from gymnasium_planar_robotics.envs.basic_envs import BasicPlanarRoboticsSingleAgentEnv
+    rng = np.random.default_rng(seed)
+    out = {'tags': np.array([c[0] for c in STEP_TEMPLATE_CONFIGS])}
+    for tag, layout, M, jerk, cp, ncyc in STEP_TEMPLATE_CONFIGS:
+        env = planning_env(layout_tiles=layout, num_movers=M, learn_jerk=jerk, collision_params=cp, num_cycles=ncyc, std_noise=0.0)
+        world = World(env, jerk).install()
+        lim = env.j_max if jerk else env.a_max
+        od = 4 * M if jerk else 2 * M
+        starts = np.zeros((E, M, 2)); goals = np.zeros((E, M, 2)); v0 = np.zeros((E, M, 2)); a0 = np.zeros((E, M, 2)); acts = np.zeros((T, E, 2 * M))
+        res = dict(observation=np.zeros((T, E, od)), achieved_goal=np.zeros((T, E, 2 * M)), desired_goal=np.zeros((T, E, 2 * M)),
+                   reward=np.zeros((T, E)), terminated=np.zeros((T, E), dtype=bool), truncated=np.zeros((T, E), dtype=bool),
+                   is_success=np.zeros((T, E), dtype=bool), mover_collision=np.zeros((T, E), dtype=bool), wall_collision=np.zeros((T, E), dtype=bool),
+                   pos=np.zeros((T, E, 2 * M)), vel=np.zeros((T, E, 2 * M)), acc=np.zeros((T, E, 2 * M)), valid=np.zeros((T, E), dtype=bool))
+        try:
+            for e in range(E):
+                # a valid, collision-free start set drawn by the reference's own reset loop (scripted uniform not needed here)
+                st, gl = reference_valid_sets(env, world, 1000 * (1000 * seed + e))
+                kind = e % 6
+                env.goals = gl.copy()
+                vv = np.zeros((M, 2)); aa = np.zeros((M, 2))
+                act = rng.uniform(-lim, lim, size=(T, 2 * M))
+                if kind == 0:    # heading for a wall: full speed towards the nearest outer edge
+                    hi = np.array([layout.shape[0], layout.shape[1]]) * 0.24
+                    for i in range(M):
+                        d = np.argmin(np.concatenate([st[i], hi - st[i]]))
+                        dirv = np.array([[-1, 0], [0, -1], [1, 0], [0, 1]][d], dtype=np.float64)
+                        vv[i] = dirv * rng.uniform(1.0, 2.0)
+                        act[:, 2 * i:2 * i + 2] = dirv * lim * rng.uniform(0.3, 1.0)
+                elif kind == 1 and M > 1:  # movers 0 and 1 on a collision course
+                    d = st[1] - st[0]; n = d / np.linalg.norm(d)
+                    vv[0] = n * 1.9; vv[1] = -n * 1.9
+                    act[:, 0:2] = n * lim * 0.5; act[:, 2:4] = -n * lim * 0.5
+                elif kind == 2:  # every mover starts inside its goal radius, at rest, tiny actions: +50 at once (goals unchecked against starts)
+                    gl = st + rng.uniform(-0.05, 0.05, size=(M, 2))
+                    act = rng.uniform(-0.02, 0.02, size=(T, 2 * M)) * lim
+                elif kind == 3:  # some reached, some not
+                    gl = st + rng.uniform(-0.05, 0.05, size=(M, 2))
+                    far = rng.integers(0, M)
+                    gl[far] = env.goals[far] if np.linalg.norm(env.goals[far] - st[far]) > 0.2 else st[far] + np.array([0.3, 0.0]) * (1 if st[far, 0] < 0.4 else -1)
+                    act = rng.uniform(-0.02, 0.02, size=(T, 2 * M)) * lim
+                elif kind == 4:  # actions far outside the action space (BE:1871-1873: clipped), speed clamp active
+                    act = rng.uniform(-5 * lim, 5 * lim, size=(T, 2 * M))
+                    vv = rng.uniform(-1.3, 1.3, size=(M, 2))
+                else:            # free flight with some initial velocity
+                    vv = rng.uniform(-0.8, 0.8, size=(M, 2))
+                if jerk:
+                    aa = rng.uniform(-6, 6, size=(M, 2))
+                starts[e], goals[e], v0[e], a0[e], acts[:, e] = st, gl, vv, aa, act
+                world.load(st); world.qvel[:, :2] = vv; world.qacc[:, :2] = aa; world.act[:] = aa
+                env.goals = gl.copy()
+                for t in range(T):
+                    try:
+                        o, r, term, trunc, info = BasicPlanarRoboticsSingleAgentEnv.step(env, act[t].copy())
+                    except AssertionError:
+                        break  # a mover above no tile at all: the reference asserts (BE:514); the engine reports a wall collision
+                    res['valid'][t, e] = True
+                    res['observation'][t, e] = o['observation']; res['achieved_goal'][t, e] = o['achieved_goal']; res['desired_goal'][t, e] = o['desired_goal']
+                    res['reward'][t, e] = r; res['terminated'][t, e] = bool(term); res['truncated'][t, e] = bool(trunc)
+                    res['is_success'][t, e] = bool(info['is_success']); res['mover_collision'][t, e] = bool(info['mover_collision'])
+                    res['wall_collision'][t, e] = bool(info['wall_collision'])
+                    res['pos'][t, e] = world.qpos[:, :2].reshape(-1); res['vel'][t, e] = world.qvel[:, :2].reshape(-1); res['acc'][t, e] = world.qacc[:, :2].reshape(-1)
+        finally:
+            world.uninstall()
+        v = res['valid']
+        print(f'step_template {tag}: {int(v.sum())} valid env-steps, wall {int(res["wall_collision"][v].sum())}, pair {int(res["mover_collision"][v].sum())}, '
+              f'+50 {int((res["reward"][v] == 50).sum())}, partial {int(((res["reward"][v] > -M) & (res["reward"][v] < 0)).sum())}, '
+              f'none {int((res["reward"][v] == -M).sum())}')
+        out[tag + '_layout'] = np.asarray(layout, dtype=np.int8); out[tag + '_M'] = np.array(M); out[tag + '_jerk'] = np.array(jerk)
+        out[tag + '_num_cycles'] = np.array(ncyc); out[tag + '_shape'] = np.array(int(cp.get('shape', 'circle') == 'box'))
+        out[tag + '_size'] = np.atleast_1d(np.asarray(cp.get('size', 0.11), dtype=np.float64))
+        out[tag + '_offset'] = np.array(cp.get('offset', 0.0)); out[tag + '_offset_wall'] = np.array(cp.get('offset_wall', 0.0))
+        out[tag + '_starts'] = starts; out[tag + '_goals'] = goals; out[tag + '_v0'] = v0; out[tag + '_a0'] = a0; out[tag + '_actions'] = acts
+        for k, a in res.items():
+            out[f'{tag}_{k}'] = a
+    np.savez_compressed(os.path.join(HERE, 'step_template.npz'), **out)
+
+
+RESET_TEMPLATE_CONFIGS = [
+    ('M4', np.ones((6, 6)), 4, {}),
+    ('M8', np.ones((5, 5)), 8, {}),
+    ('M3_holes', np.array([[1, 1, 1, 1], [1, 1, 0, 1], [1, 1, 1, 1], [1, 0, 1, 1]]), 3, {'offset': 0.01, 'offset_wall': 0.002}),
+    ('M2_box', np.ones((3, 3)), 2, {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.005}),
+]
+
+
+def gen_reset_template(seed=61, E=40, K=32):
+    """E scripted resets per configuration. reset() is called as written with np_random.uniform scripted to hand out ONE prescribed
+    stream of K candidate sets (the start loop consumes from it until it accepts, the goal loop goes on from there -- exactly how the
+    two loops share np_random); the fixture holds the stream and what reset() made of it: how many sets it consumed, the accepted
+    starts and goals, the initial observation and info. Candidate sets include positions outside the sampling box (a scripted sampler
+    can return them; the loops must reject them through qpos_is_valid), overlapping movers, goals closer than min_goal_dist, and a goal
+    set that equals the accepted start set (accepted: goals are not checked against starts). A set known to be valid sits at a random
+    place of the stream's first half and valid goal sets fill its tail, so both loops end inside the script."""
+    from gymnasium_planar_robotics.envs.basic_envs import BasicPlanarRoboticsSingleAgentEnv
+    rng = np.random.default_rng(seed)
+    out = {'tags': np.array([c[0] for c in RESET_TEMPLATE_CONFIGS])}
+    for tag, layout, M, cp in RESET_TEMPLATE_CONFIGS:
+        env = planning_env(layout_tiles=layout, num_movers=M, collision_params=cp, std_noise=0.0)
+        world = World(env, False).install()
+        cand = np.zeros((E, K, M, 2)); n_used = np.zeros(E, dtype=np.int32)
+        st = np.zeros((E, 2 * M)); gl = np.zeros((E, 2 * M))
+        obs = np.zeros((E, 2 * M)); ag = np.zeros((E, 2 * M)); dg = np.zeros((E, 2 * M))
+        succ = np.zeros(E, dtype=bool); mc = np.zeros(E, dtype=bool); wc = np.zeros(E, dtype=bool)
+        lows = np.zeros((E, 2)); highs = np.zeros((E, 2))
+        try:
+            for e in range(E):
+                good_s, good_g = reference_valid_sets(env, world, 1000 * (7000 + 100 * seed + e))  # from the reference's own, unscripted loop
+                span = env.max_xy_pos - env.min_xy_pos
+                for k in range(K):  # squeezed into a corner of the sampling box (many overlaps) or spread out; some leave the box
+                    cand[e, k] = env.min_xy_pos + rng.uniform(size=(M, 2)) * span * rng.choice([0.3, 0.6, 1.0, 1.0])
+                    if rng.uniform() < 0.2:
+                        i = rng.integers(0, M)
+                        cand[e, k, i] = np.clip(cand[e, k, i] - rng.choice([[0.3, 0.0], [0.0, 0.3]]), 0.001, None)  # (still above a cell: BE:514 asserts otherwise)
+                    while not reference_accepts_without_assert(env, cand[e, k]):  # (BE:650 can fire near two missing tiles: not a case to pin)
+                        cand[e, k] = env.min_xy_pos + rng.uniform(size=(M, 2)) * span
+                ks = 0 if e % 5 == 0 else int(rng.integers(0, K // 2))
+                cand[e, ks] = good_s
+                if e % 5 == 0:
+                    cand[e, 1] = good_s  # the goal loop's first candidate is the accepted start set itself
+                cand[e, K - K // 4:] = good_g
+                script = ScriptedUniform(list(cand[e]))
+                env.np_random = script
+                # reset(seed=None): gym.Env.reset leaves np_random alone; the template then calls _reset_callback, mj_forward, the two
+                # initial checks, _get_obs, _get_info -- all as written
+                o, info = BasicPlanarRoboticsSingleAgentEnv.reset(env, seed=None, options=None)
+                n_used[e] = len(script.calls)
+                st[e] = world.qpos[:, :2].reshape(-1); gl[e] = env.goals.reshape(-1)
+                obs[e], ag[e], dg[e] = o['observation'], o['achieved_goal'], o['desired_goal']
+                succ[e], mc[e], wc[e] = bool(info['is_success']), bool(info['mover_collision']), bool(info['wall_collision'])
+                lows[e], highs[e] = script.calls[0][0], script.calls[0][1]
+                assert all(c[2] == (M, 2) and np.array_equal(c[0], lows[e]) and np.array_equal(c[1], highs[e]) for c in script.calls)
+                assert np.array_equal(gl[e], cand[e, n_used[e] - 1].reshape(-1))
+        finally:
+            world.uninstall()
+        print(f'reset_template {tag}: sets consumed {n_used.min()}..{n_used.max()} (mean {n_used.mean():.1f}), goals == starts accepted in '
+              f'{int(np.sum(np.all(gl == st, axis=1)))} resets, initial flags set in {int((mc | wc).sum())}')
+        out[tag + '_layout'] = np.asarray(layout, dtype=np.int8); out[tag + '_M'] = np.array(M)
+        out[tag + '_shape'] = np.array(int(cp.get('shape', 'circle') == 'box')); out[tag + '_size'] = np.atleast_1d(np.asarray(cp.get('size', 0.11), dtype=np.float64))
+        out[tag + '_offset'] = np.array(cp.get('offset', 0.0)); out[tag + '_offset_wall'] = np.array(cp.get('offset_wall', 0.0))
+        out[tag + '_cand'] = cand; out[tag + '_n_used'] = n_used
+        out[tag + '_starts'] = st; out[tag + '_goals'] = gl; out[tag + '_observation'] = obs; out[tag + '_achieved_goal'] = ag; out[tag + '_desired_goal'] = dg
+        out[tag + '_is_success'] = succ; out[tag + '_mover_collision'] = mc; out[tag + '_wall_collision'] = wc
+        out[tag + '_uniform_low'] = lows; out[tag + '_uniform_high'] = highs
+    np.savez_compressed(os.path.join(HERE, 'reset_template.npz'), **out)
+
+
+PUSH_KW = dict(render_mode=None, std_noise=0.0)
+
+
+def gen_pushing_methods(seed=71):
+    """BenchmarkPushingEnv's own methods as written (row a16; everything except MuJoCo's contact solve and the impedance hold):
+    _get_obs (acc + jerk), compute_reward / compute_terminated on arrays of info dicts incl. dist == threshold, and
+    reset() + _reset_callback with a scripted np_random.uniform, with and without the options."""
+    from gymnasium_planar_robotics.envs.basic_envs import BasicPlanarRoboticsSingleAgentEnv
+    rng = np.random.default_rng(seed)
+    out = {}
+    # ---- _get_obs ----
+    for jerk in (False, True):
+        env = BenchmarkPushingEnv(learn_jerk=jerk, **PUSH_KW)
+        env.object_noise_xy_pos = 0.0
+        world = World(env, jerk).install()
+        n = 40
+        pos = rng.uniform(0.12, 0.6, size=(n, 2)); vel = rng.uniform(-2, 2, size=(n, 2)); acc = rng.uniform(-10, 10, size=(n, 2))
+        obj = rng.uniform(0.2, 0.5, size=(n, 2)); goal = rng.uniform(0.2, 0.5, size=(n, 2))
+        obs = np.zeros((n, 6 if jerk else 4)); ag = np.zeros((n, 2)); dg = np.zeros((n, 2))
+        try:
+            for i in range(n):
+                world.qpos[0, :2] = pos[i]; world.qvel[0, :2] = vel[i]; world.qacc[0, :2] = acc[i]; world.object_qpos[:2] = obj[i]
+                env.object_xy_goal_pos = goal[i].copy()
+                o = BenchmarkPushingEnv._get_obs(env)
+                obs[i], ag[i], dg[i] = o['observation'], o['achieved_goal'], o['desired_goal']
+        finally:
+            world.uninstall()
+        tag = 'obs_jerk' if jerk else 'obs_acc'
+        out.update({tag + '_pos': pos, tag + '_vel': vel, tag + '_acc': acc, tag + '_object': obj, tag + '_goal': goal,
+                    tag + '_observation': obs, tag + '_achieved_goal': ag, tag + '_desired_goal': dg})
+    # ---- compute_reward / compute_terminated ----
+    env = BenchmarkPushingEnv(**PUSH_KW)
+    n = 600
+    ag = rng.uniform(0.2, 0.5, size=(n, 2)); dg = ag + rng.uniform(-0.08, 0.08, size=(n, 2))
+    ang = rng.uniform(0, 2 * np.pi, size=100)
+    dg[:100] = ag[:100] + env.threshold_pos * np.stack([np.cos(ang), np.sin(ang)], axis=1)  # dist == threshold up to rounding: either side
+    dg[100:120] = ag[100:120] + np.array([env.threshold_pos, 0.0])
+    wcol = rng.uniform(size=n) < 0.3
+    infos = np.array([{'is_success': False, 'mover_collision': False, 'wall_collision': bool(w)} for w in wcol])
+    rew = np.asarray(env.compute_reward(achieved_goal=ag, desired_goal=dg, info=infos), dtype=np.float64)
+    term = np.asarray(env.compute_terminated(achieved_goal=ag, desired_goal=dg, info=infos), dtype=bool)
+    r1 = np.array([env.compute_reward(achieved_goal=ag[i], desired_goal=dg[i], info=infos[i]) for i in range(20)])
+    assert np.array_equal(r1, rew[:20])
+    out.update({'reward_ag': ag, 'reward_dg': dg, 'reward_wc': wcol, 'reward_reward': rew, 'reward_terminated': term,
+                'reward_threshold_pos': np.array(env.threshold_pos)})
+    # ---- reset() + _reset_callback, scripted ----
+    E, K = 60, 24
+    env = BenchmarkPushingEnv(**PUSH_KW)
+    env.object_noise_xy_pos = 0.0
+    world = World(env, False).install()
+    mover_draw = np.zeros((E, 2)); obj_cand = np.zeros((E, K, 2)); goal_draw = np.zeros((E, 2))
+    opt_start = np.full((E, 2), np.nan); opt_goal = np.full((E, 2), np.nan)
+    n_obj = np.zeros(E, dtype=np.int32)
+    mstart = np.zeros((E, 2)); ostart = np.zeros((E, 2)); ogoal = np.zeros((E, 2)); obs = np.zeros((E, 4)); ag = np.zeros((E, 2)); dg = np.zeros((E, 2))
+    succ = np.zeros(E, dtype=bool); wc = np.zeros(E, dtype=bool)
+    bounds = {}
+    try:
+        for e in range(E):
+            mover_draw[e] = rng.uniform(env.min_xy_pos, env.max_xy_pos)
+            goal_draw[e] = rng.uniform(env.object_min_xy_pos, env.object_max_xy_pos)
+            options = {}
+            if e % 4 == 1 or e % 4 == 3:
+                opt_start[e] = rng.uniform(env.min_xy_pos, env.max_xy_pos); options['mover_start_xy_pos'] = opt_start[e].copy()
+            if e % 4 == 2 or e % 4 == 3:
+                opt_goal[e] = rng.uniform(env.object_min_xy_pos, env.object_max_xy_pos); options['object_goal_xy_pos'] = opt_goal[e].copy()
+            mv = opt_start[e] if 'mover_start_xy_pos' in options else mover_draw[e]
+            # object candidates: some within min_mo_dist of the mover (rejected, PU:407: strictly greater), one exactly at a distance
+            # computed as min_mo_dist (either side of the rounding), the last ones far away
+            for k in range(K):
+                obj_cand[e, k] = rng.uniform(env.object_min_xy_pos, env.object_max_xy_pos)
+            near = mv + rng.uniform(-0.08, 0.08, size=(3, 2))
+            obj_cand[e, :3] = near
+            a = rng.uniform(0, 2 * np.pi)
+            obj_cand[e, 3] = mv + env.min_mo_dist * np.array([np.cos(a), np.sin(a)])
+            far = np.where(mv < 0.33, env.object_max_xy_pos, env.object_min_xy_pos)
+            obj_cand[e, K - 4:] = far
+            script = ScriptedUniform([mover_draw[e].reshape(1, 2)] + [c.reshape(1, 2) for c in obj_cand[e]])
+            # the goal draw comes after the object loop: the script hands it out as "the next sample", whatever the loop consumed
+
+            class Stream:
+                def __init__(self):
+                    self.calls, self.n_obj = [], 0
+
+                def uniform(self, low, high, size=None):
+                    size_t = tuple(np.atleast_1d(size))
+                    self.calls.append((np.array(low, dtype=np.float64), np.array(high, dtype=np.float64), size_t))
+                    if len(self.calls) == 1:
+                        return mover_draw[e].reshape(size_t).copy()        # PU:389-391 (drawn even when the option is given)
+                    if size_t == (2,):
+                        return goal_draw[e].copy()                          # PU:412-414 (drawn even when the option is given)
+                    self.n_obj += 1
+                    return obj_cand[e, self.n_obj - 1].reshape(size_t).copy()  # PU:403-405
+
+            stream = Stream()
+            env.np_random = stream
+            o, info = BasicPlanarRoboticsSingleAgentEnv.reset(env, seed=None, options=options if options else None)
+            n_obj[e] = stream.n_obj
+            mstart[e] = world.qpos[0, :2]; ostart[e] = np.asarray(env.object_xy_start_pos).reshape(-1); ogoal[e] = np.asarray(env.object_xy_goal_pos).reshape(-1)
+            world.object_qpos[:2] = ostart[e]  # (what compiling reload_model's MJCF yields for the object body)
+            o = BenchmarkPushingEnv._get_obs(env)
+            obs[e], ag[e], dg[e] = o['observation'], o['achieved_goal'], o['desired_goal']
+            succ[e], wc[e] = bool(info['is_success']), bool(info['wall_collision'])
+            assert not info['mover_collision']
+            bounds = {'mover_low': stream.calls[0][0], 'mover_high': stream.calls[0][1], 'object_low': stream.calls[1][0], 'object_high': stream.calls[1][1]}
+            assert stream.calls[-1][2] == (2,) and len(stream.calls) == 2 + n_obj[e]
+    finally:
+        world.uninstall()
+    print(f'pushing reset: object trials {n_obj.min()}..{n_obj.max()} (mean {n_obj.mean():.1f}); initial wall flags {int(wc.sum())}')
+    out.update({'reset_mover_draw': mover_draw, 'reset_object_cand': obj_cand, 'reset_goal_draw': goal_draw, 'reset_opt_start': opt_start,
+                'reset_opt_goal': opt_goal, 'reset_n_object': n_obj, 'reset_mover_start': mstart, 'reset_object_start': ostart,
+                'reset_object_goal': ogoal, 'reset_observation': obs, 'reset_achieved_goal': ag, 'reset_desired_goal': dg,
+                'reset_wall_collision': wc, 'reset_min_mo_dist': np.array(env.min_mo_dist),
+                **{'reset_' + k: v for k, v in bounds.items()}})
+    np.savez_compressed(os.path.join(HERE, 'pushing_methods.npz'), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'round3':  # only the fixtures added in round 3
+        gen_step_template()
+        gen_reset_template()
+        gen_pushing_methods()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'round2':  # only the fixtures added in round 2 (the others are unchanged)
         gen_obs_ordering()
         gen_step_callback()
@@ -606,3 +1006,6 @@ if __name__ == '__main__':
     gen_reset_predicates()
     gen_obs_ordering()
     gen_step_callback()
+    gen_step_template()
+    gen_reset_template()
+    gen_pushing_methods()

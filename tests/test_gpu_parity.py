@@ -751,3 +751,96 @@ def test_step_n_equals_n_steps(gpr, M, n, E, kw):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert a.get_rng_state() == b.get_rng_state()
     a.close(); b.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 3: the step() / reset() TEMPLATES as the reference's methods execute them (tests/golden/step_template.npz, reset_template.npz:
+# BasicPlanarRoboticsSingleAgentEnv.step / .reset and BenchmarkPlanningEnv._reset_callback called as written on a stand-in world),
+# through the C ABI. tests/test_oracle_golden.py holds the oracle to the same fixtures bit for bit.
+# ----------------------------------------------------------------------------------------------------------------------
+def _template_cp(z, tag):
+    box = bool(z[f'{tag}_shape'])
+    return {'shape': 'box' if box else 'circle', 'size': z[f'{tag}_size'] if box else float(z[f'{tag}_size'][0]),
+            'offset': float(z[f'{tag}_offset']), 'offset_wall': float(z[f'{tag}_offset_wall'])}
+
+
+@pytest.mark.parametrize('precision', ['f64', 'f32_f64acc', 'f32'])
+def test_step_template_matches_reference_step(gpr, precision):
+    """the cycle loop's break, the state / flags / observation of the colliding cycle, reward, terminated, info, the clip (BE:1835-1950)"""
+    z = load_npz('step_template.npz')
+    exact = precision == 'f64'
+    worst, n_cmp, n_flag_off = 0.0, 0, 0
+    for tag in z['tags']:
+        M, jerk, E = int(z[f'{tag}_M']), bool(z[f'{tag}_jerk']), z[f'{tag}_starts'].shape[0]
+        env = gpr.VecBenchmarkPlanningEnv(z[f'{tag}_layout'], M, num_envs=E, precision=precision, std_noise=0.0, autoreset_mode='disabled',
+                                          max_episode_steps=None, learn_jerk=jerk, num_cycles=int(z[f'{tag}_num_cycles']),
+                                          collision_params=_template_cp(z, tag))
+        env.reset(seed=0)
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a).reshape(E, -1), device=env.device).to(env.dtype)  # noqa: E731
+        env.pos.copy_(dev(z[f'{tag}_starts'])); env.vel.copy_(dev(z[f'{tag}_v0'])); env.acc.copy_(dev(z[f'{tag}_a0'])); env.goals.copy_(dev(z[f'{tag}_goals']))
+        follow = np.ones(E, dtype=bool)  # envs that are valid in the fixture and (float builds) have decided like the reference so far
+        for t in range(z[f'{tag}_actions'].shape[0]):
+            obs, rew, term, trunc, info = env.step(dev(z[f'{tag}_actions'][t]))
+            follow &= z[f'{tag}_valid'][t]
+            got = {'reward': rew, 'terminated': term, 'truncated': trunc, **{k: info[k] for k in ('is_success', 'mover_collision', 'wall_collision')}}
+            same = np.ones(E, dtype=bool)
+            for k, v in got.items():
+                same &= v.double().cpu().numpy() == z[f'{tag}_{k}'][t].astype(np.float64)
+            if exact:
+                assert same[follow].all(), (tag, t)
+            n_flag_off += int((~same & follow).sum()); n_cmp += int(follow.sum())
+            follow &= same
+            for k, ref in (('observation', obs['observation']), ('achieved_goal', obs['achieved_goal']), ('desired_goal', obs['desired_goal']),
+                           ('pos', env.pos), ('vel', env.vel)) + ((('acc', env.acc),) if jerk else ()):
+                d = np.abs(ref.double().cpu().numpy() - z[f'{tag}_{k}'][t])[follow]
+                worst = max(worst, float(d.max()) if d.size else 0.0)
+        env.close()
+    record_metric(f'step_template[{precision}]', max_abs_err=worst, env_steps_compared=n_cmp, env_steps_deciding_differently=n_flag_off,
+                  tol=1e-12 if exact else 1e-4)
+    assert worst < (1e-12 if exact else 1e-4), worst
+    assert n_flag_off <= (0 if exact else 0.01 * n_cmp), (n_flag_off, n_cmp)  # float builds: a scenario within float rounding of a threshold
+
+
+@pytest.mark.parametrize('precision', ['f64', 'f32'])
+def test_reset_template_matches_reference_reset(gpr, oracle, precision):
+    """reset() + _reset_callback as written on a scripted np_random.uniform, replayed through gpr_reset_candidates: the first valid set of
+    the stream wins, the goal loop goes on from there, goals are not checked against starts (PL:355-418, BE:1770-1833)"""
+    z = load_npz('reset_template.npz')
+    for tag in z['tags']:
+        M, cand = int(z[f'{tag}_M']), z[f'{tag}_cand']
+        E = cand.shape[0]
+        env = gpr.VecBenchmarkPlanningEnv(z[f'{tag}_layout'], M, num_envs=E, precision=precision, std_noise=0.0, autoreset_mode='disabled',
+                                          max_episode_steps=None, collision_params=_template_cp(z, tag))
+        stream = np.ascontiguousarray(np.swapaxes(cand, 0, 1))
+        obs, info = env.reset(seed=0, options={'candidates': stream})
+        if precision == 'f64':
+            assert np.array_equal(info['candidates_used'].cpu().numpy(), z[f'{tag}_n_used']), tag
+            assert np.array_equal(env.pos.cpu().numpy(), z[f'{tag}_starts']) and np.array_equal(env.goals.cpu().numpy(), z[f'{tag}_goals']), tag
+            for k in ('observation', 'achieved_goal', 'desired_goal'):
+                assert np.array_equal(obs[k].cpu().numpy(), z[f'{tag}_{k}']), (tag, k)
+            for k in ('is_success', 'mover_collision', 'wall_collision'):
+                assert np.array_equal(info[k].cpu().numpy(), z[f'{tag}_{k}']), (tag, k)
+        else:  # float storage: the candidates themselves are rounded to float; the oracle with float storage is the yardstick
+            ref = oracle.OraclePlanningEnv(z[f'{tag}_layout'], M, E, std_noise=0.0, collision_params=_template_cp(z, tag), autoreset='disabled',
+                                           max_episode_steps=None, storage_f32=True)
+            o, n_used = ref.reset_candidates(stream.astype(np.float32).astype(np.float64))
+            same = info['candidates_used'].cpu().numpy() == n_used
+            assert same.mean() > 0.9, (tag, same.mean())  # (a float-rounded candidate can sit on a threshold)
+            assert np.array_equal(env.pos.double().cpu().numpy()[same], ref.pos[same]) and np.array_equal(env.goals.double().cpu().numpy()[same], ref.goal[same])
+        assert not env.vel.any() and not env.elapsed_steps.any()
+        env.close()
+    # a stream that runs out: the last set stands (as max_reset_trials does), for the start loop and for the goal loop
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((4, 4)), 2, num_envs=3, precision=precision, std_noise=0.0)
+    bad = np.array([[0.3, 0.3], [0.3, 0.3]]); ok1 = np.array([[0.3, 0.3], [0.7, 0.7]]); ok2 = np.array([[0.5, 0.2], [0.2, 0.6]])
+    stream = np.stack([np.stack([bad, ok1, ok1]), np.stack([bad, bad, ok2]), np.stack([bad, bad, bad])])  # [n_cand = 3][E = 3][M][2]
+    obs, info = env.reset(seed=0, options={'candidates': stream})
+    want_pos = np.stack([bad, ok1, ok1]).reshape(3, -1); want_goal = np.stack([bad, bad, ok2]).reshape(3, -1)
+    want_pos[0] = bad.reshape(-1); want_goal[0] = bad.reshape(-1)      # env 0: nothing valid -> start = last set, goal = last set
+    want_pos[1] = ok1.reshape(-1); want_goal[1] = bad.reshape(-1)      # env 1: start accepted as set 0, goals bad, bad -> the last stands
+    want_pos[2] = ok1.reshape(-1); want_goal[2] = ok2.reshape(-1)      # env 2: start = set 0, goal: set 1 (ok2)
+    want_pos[0] = bad.reshape(-1)
+    got_used = info['candidates_used'].cpu().numpy()
+    assert np.allclose(env.pos.double().cpu().numpy()[1:], want_pos[1:], atol=1e-6) and np.allclose(env.goals.double().cpu().numpy()[1:], want_goal[1:], atol=1e-6)
+    assert np.allclose(env.pos.double().cpu().numpy()[0], bad.reshape(-1), atol=1e-6) and np.allclose(env.goals.double().cpu().numpy()[0], bad.reshape(-1), atol=1e-6)
+    assert got_used.tolist() == [3, 3, 2], got_used
+    env.close()

@@ -256,3 +256,52 @@ def test_two_mover_pushing_semantics(gpr):
             assert ((fo[:, 0] - fo[:, 1]).norm(dim=1) <= 0.22 + 1e-3).all()           # they really met (BE:409)
     assert n_mc > 100 and n_wc > 100 and n_push > 1000, (n_mc, n_wc, n_push)
     env.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 3: BenchmarkPushingEnv's own methods as written (tests/golden/pushing_methods.npz), through the C ABI
+# ----------------------------------------------------------------------------------------------------------------------
+def test_pushing_methods_match_reference(gpr):
+    """_get_obs (PU:529-576), compute_reward / compute_terminated on arrays of info dicts (PU:457-527), reset() + _reset_callback with a
+    scripted generator and the two options (PU:373-417)"""
+    z = load_npz('pushing_methods.npz')
+    mk = lambda n, **kw: gpr.VecBenchmarkPushingEnv(num_envs=n, precision='f64', std_noise=0.0, _push_overrides={'object_noise': 0.0}, autoreset_mode='disabled',  # noqa: E731
+                                                    max_episode_steps=None, **kw)
+    for mode in ('acc', 'jerk'):
+        t = f'obs_{mode}'
+        n = z[f'{t}_pos'].shape[0]
+        env = mk(n, learn_jerk=(mode == 'jerk'), num_cycles=0)
+        env.reset(seed=0)
+        dev = lambda a: torch.as_tensor(a, device=env.device)  # noqa: E731
+        env.pos.copy_(dev(z[f'{t}_pos'])); env.vel.copy_(dev(z[f'{t}_vel'])); env.acc.copy_(dev(z[f'{t}_acc']))
+        env.object[:, :2] = dev(z[f'{t}_object']); env.goals.copy_(dev(z[f'{t}_goal']))
+        obs, *_ = env.step(torch.zeros(n, 2, dtype=env.dtype, device=env.device))
+        for k in ('observation', 'achieved_goal', 'desired_goal'):
+            assert np.array_equal(obs[k].cpu().numpy(), z[f'{t}_{k}']), (t, k)
+        env.close()
+    # HER API on the reference's calling convention: an array of info dicts
+    ag, dg, wc = z['reward_ag'], z['reward_dg'], z['reward_wc']
+    env = mk(4, threshold_pos=float(z['reward_threshold_pos']))
+    infos = np.array([{'is_success': False, 'mover_collision': False, 'wall_collision': bool(w)} for w in wc])
+    assert np.array_equal(env.compute_reward(ag, dg, infos).double().cpu().numpy(), z['reward_reward'])
+    assert np.array_equal(env.compute_terminated(ag, dg, infos).cpu().numpy(), z['reward_terminated'])
+    r1 = env.compute_reward(ag[7], dg[7], infos[7])
+    assert r1.ndim == 0 and float(r1) == z['reward_reward'][7]
+    env.close()
+    # reset(): scripted object candidates, with / without the options
+    cand = z['reset_object_cand']
+    opt_s, opt_g = z['reset_opt_start'], z['reset_opt_goal']
+    for has_s in (False, True):
+        for has_g in (False, True):
+            idx = np.nonzero((~np.isnan(opt_s[:, 0]) == has_s) & (~np.isnan(opt_g[:, 0]) == has_g))[0]
+            env = mk(len(idx))
+            ms = np.where(has_s, opt_s[idx], z['reset_mover_draw'][idx]); og = np.where(has_g, opt_g[idx], z['reset_goal_draw'][idx])
+            obs, info = env.reset(seed=0, options={'mover_start_xy_pos': ms.reshape(len(idx), 1, 2), 'object_goal_xy_pos': og,
+                                                   'object_candidates': np.ascontiguousarray(np.swapaxes(cand[idx], 0, 1))})
+            assert np.array_equal(info['candidates_used'].cpu().numpy(), z['reset_n_object'][idx]), (has_s, has_g)
+            assert np.array_equal(env.pos.cpu().numpy(), z['reset_mover_start'][idx]) and np.array_equal(env.object[:, :2].cpu().numpy(), z['reset_object_start'][idx])
+            assert np.array_equal(env.goals.cpu().numpy(), z['reset_object_goal'][idx])
+            for k in ('observation', 'achieved_goal', 'desired_goal'):
+                assert np.array_equal(obs[k].cpu().numpy(), z[f'reset_{k}'][idx]), k
+            assert np.array_equal(info['wall_collision'].cpu().numpy(), z['reset_wall_collision'][idx])
+            env.close()

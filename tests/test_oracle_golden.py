@@ -193,3 +193,116 @@ def test_control_decision(oracle, mode):
     got = (((env.acc if mode == 'jerk' else env.vel) - before) / dt).reshape(n, M, 2)
     assert np.abs(got - ctrl).max() < 1e-8 * (100.0 if mode == 'jerk' else 10.0)
     assert (np.abs(ctrl.reshape(n, -1) - act).max(axis=1) > 1e-9).mean() > 0.4  # the fixture really exercises the clamps
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 3: the step() / reset() TEMPLATES (BE:1770-1950, PL:355-418) and the pushing env's own methods (PU:373-607), from the reference's
+# methods called as written on a stand-in world (tests/golden/make_golden.py: World) -- control flow, not mj_step
+# ----------------------------------------------------------------------------------------------------------------------
+def template_cp(z, tag):
+    box = bool(z[f'{tag}_shape'])
+    return {'shape': 'box' if box else 'circle', 'size': z[f'{tag}_size'] if box else float(z[f'{tag}_size'][0]),
+            'offset': float(z[f'{tag}_offset']), 'offset_wall': float(z[f'{tag}_offset_wall'])}
+
+
+STEP_KEYS = ('observation', 'achieved_goal', 'desired_goal', 'reward', 'terminated', 'truncated', 'is_success', 'mover_collision',
+             'wall_collision')
+
+
+def test_step_template(oracle):
+    """step() as written: the cycle loop breaks at the first collision and returns the state, flags and observation of that cycle
+    (BE:1879-1905), reward -50 / +50 / -(M - n_reached), terminated, info; actions outside the action space are clipped (BE:1871-1873).
+    T consecutive calls per scenario, also past a termination (the template does not care). Bit for bit."""
+    z = load_npz('step_template.npz')
+    seen = dict(wall=0, pair=0, success=0, partial=0)
+    for tag in z['tags']:
+        M, jerk, E = int(z[f'{tag}_M']), bool(z[f'{tag}_jerk']), z[f'{tag}_starts'].shape[0]
+        env = oracle.OraclePlanningEnv(z[f'{tag}_layout'], M, E, std_noise=0.0, num_cycles=int(z[f'{tag}_num_cycles']), learn_jerk=jerk,
+                                       collision_params=template_cp(z, tag), autoreset='disabled', max_episode_steps=None)
+        env.pos[:] = z[f'{tag}_starts'].reshape(E, -1); env.vel[:] = z[f'{tag}_v0'].reshape(E, -1); env.acc[:] = z[f'{tag}_a0'].reshape(E, -1)
+        env.goal[:] = z[f'{tag}_goals'].reshape(E, -1)
+        alive = np.ones(E, dtype=bool)
+        for t in range(z[f'{tag}_actions'].shape[0]):
+            o = env.step(z[f'{tag}_actions'][t])
+            alive &= z[f'{tag}_valid'][t]  # (a mover above no tile at all: the reference asserts, BE:514 -- nothing to compare from then on)
+            for k in STEP_KEYS:
+                assert np.array_equal(o[k][alive], z[f'{tag}_{k}'][t][alive]), (tag, t, k)
+            assert np.array_equal(env.pos[alive], z[f'{tag}_pos'][t][alive]) and np.array_equal(env.vel[alive], z[f'{tag}_vel'][t][alive]), (tag, t)
+            assert np.array_equal(env.acc[alive], z[f'{tag}_acc'][t][alive]), (tag, t)
+            seen['wall'] += int(o['wall_collision'][alive].sum()); seen['pair'] += int(o['mover_collision'][alive].sum())
+            seen['success'] += int(o['is_success'][alive].sum()); seen['partial'] += int(((o['reward'] > -M) & (o['reward'] < 0))[alive].sum())
+    assert min(seen.values()) > 100, seen  # every exit of the template is exercised
+
+
+def test_reset_template(oracle):
+    """reset() + _reset_callback as written on a scripted np_random.uniform: the first valid start set of the stream wins, the goal loop
+    goes on from there, goals are not checked against the starts; initial flags, observation and info (BE:1797-1831). Bit for bit."""
+    z = load_npz('reset_template.npz')
+    for tag in z['tags']:
+        M, cand = int(z[f'{tag}_M']), z[f'{tag}_cand']
+        E = cand.shape[0]
+        env = oracle.OraclePlanningEnv(z[f'{tag}_layout'], M, E, std_noise=0.0, collision_params=template_cp(z, tag), autoreset='disabled',
+                                       max_episode_steps=None)
+        assert np.array_equal(env.min_xy, z[f'{tag}_uniform_low'][0]) and np.array_equal(env.max_xy, z[f'{tag}_uniform_high'][0])  # PL:377
+        o, n_used = env.reset_candidates(np.swapaxes(cand, 0, 1))
+        assert np.array_equal(n_used, z[f'{tag}_n_used']), tag
+        assert np.array_equal(env.pos, z[f'{tag}_starts']) and np.array_equal(env.goal, z[f'{tag}_goals']), tag
+        assert not env.vel.any() and not env.acc.any() and not env.elapsed.any()
+        for k in ('observation', 'achieved_goal', 'desired_goal', 'is_success', 'mover_collision', 'wall_collision'):
+            assert np.array_equal(o[k], z[f'{tag}_{k}']), (tag, k)
+        assert (z[f'{tag}_n_used'] > 2).mean() > 0.5  # most resets reject at least one set
+        assert np.all(env.goal == env.pos, axis=1).sum() >= 5  # "goals == starts" accepted (goals unchecked against starts)
+
+
+def push_reward_mover_positions(ag, wc):
+    """a mover position per env that is out of the object's reach: over the wall margin (x = 0.05) where the case wants a wall collision,
+    else in the corner of the safe area farthest from the object"""
+    far = np.where(ag < 0.36, 0.60, 0.12)
+    hit = np.stack([np.full(len(ag), 0.05), far[:, 1]], axis=1)
+    return np.where(wc[:, None], hit, far)
+
+
+def test_pushing_methods(oracle):
+    """BenchmarkPushingEnv._get_obs / compute_reward / compute_terminated / reset() + _reset_callback as written (PU:373-607)"""
+    z = load_npz('pushing_methods.npz')
+    for mode in ('acc', 'jerk'):
+        t = f'obs_{mode}'
+        n = z[f'{t}_pos'].shape[0]
+        env = oracle.OraclePushingEnv(n, std_noise=0.0, object_noise=0.0, num_cycles=0, learn_jerk=(mode == 'jerk'), autoreset='disabled',
+                                      max_episode_steps=None)
+        env.pos[:] = z[f'{t}_pos']; env.vel[:] = z[f'{t}_vel']; env.acc[:] = z[f'{t}_acc']; env.object[:, :2] = z[f'{t}_object']; env.goal[:] = z[f'{t}_goal']
+        o = env.step(np.zeros((n, 2)))
+        for k in ('observation', 'achieved_goal', 'desired_goal'):
+            assert np.array_equal(o[k], z[f'{t}_{k}']), (t, k)
+    # reward / terminated through the observation path: the object sits at `ag`, the goal at `dg`, the wall flag comes from a mover
+    # parked outside the grid's safe area (wall collision) or well inside it
+    ag, dg, wc = z['reward_ag'], z['reward_dg'], z['reward_wc']
+    n = ag.shape[0]
+    env = oracle.OraclePushingEnv(n, std_noise=0.0, object_noise=0.0, num_cycles=1, autoreset='disabled', max_episode_steps=None,
+                                  threshold_pos=float(z['reward_threshold_pos']))
+    env.pos[:] = push_reward_mover_positions(ag, wc); env.object[:, :2] = ag; env.goal[:] = dg
+    o = env.step(np.zeros((n, 2)))
+    assert np.array_equal(o['wall_collision'], wc) and np.array_equal(o['achieved_goal'], ag)
+    assert np.array_equal(o['reward'], z['reward_reward']) and np.array_equal(o['terminated'], z['reward_terminated'])
+    assert set(np.unique(z['reward_reward'])) == {-50.0, -1.0, 0.0}
+    # reset(): scripted object candidates, with / without the two options (PU:389-391, 412-414)
+    cand = z['reset_object_cand']; E = cand.shape[0]
+    opt_s, opt_g = z['reset_opt_start'], z['reset_opt_goal']
+    for has_s in (False, True):
+        for has_g in (False, True):
+            sel = (~np.isnan(opt_s[:, 0]) == has_s) & (~np.isnan(opt_g[:, 0]) == has_g)
+            idx = np.nonzero(sel)[0]
+            assert len(idx) >= 10
+            env = oracle.OraclePushingEnv(len(idx), std_noise=0.0, object_noise=0.0, autoreset='disabled', max_episode_steps=None)
+            assert np.array_equal(env.min_xy, z['reset_mover_low']) and np.array_equal(env.max_xy, z['reset_mover_high'])
+            assert np.array_equal(env.obj_min, z['reset_object_low']) and np.array_equal(env.obj_max, z['reset_object_high'])
+            assert env.min_mo_dist == float(z['reset_min_mo_dist'])
+            # what is not given as an option was drawn by the (scripted) generator: hand the draws in through the same door
+            ms = np.where(has_s, opt_s[idx], z['reset_mover_draw'][idx]); og = np.where(has_g, opt_g[idx], z['reset_goal_draw'][idx])
+            o, n_used = env.reset_candidates(np.swapaxes(cand[idx], 0, 1), mover_start_xy_pos=ms, object_goal_xy_pos=og)
+            assert np.array_equal(n_used, z['reset_n_object'][idx]), (has_s, has_g)
+            assert np.array_equal(env.pos, z['reset_mover_start'][idx]) and np.array_equal(env.object[:, :2], z['reset_object_start'][idx])
+            assert np.array_equal(env.goal, z['reset_object_goal'][idx])
+            for k in ('observation', 'achieved_goal', 'desired_goal', 'wall_collision'):
+                assert np.array_equal(o[k], z[f'reset_{k}'][idx]), k
+    assert (z['reset_n_object'] >= 4).all()  # the three near candidates and (mostly) the one at min_mo_dist are rejected (PU:407: strictly greater)
