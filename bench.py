@@ -4,28 +4,33 @@
     python bench.py --gpus N --steps K --warmup W            # N > 1 without a launcher: this process spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one env-step of every env of every rank: ONE fused HIP kernel launch per rank per step (clip -> 40 control
-cycles of clamp / integrate / wall check / pair sweep -> observation, reward, done flags -> same-step auto-reset), i.e. what
-`VecBenchmarkPlanningEnv.step()` does, with the outputs written straight into a [T = 50, E, .] rollout buffer. Inputs
-(a ring of pre-generated random actions) are resident in HBM before the timed region. Episode phases are desynchronised
-before the warm-up (elapsed-step counters drawn uniformly from [0, 50)), so that even a short timed window sees the
-steady-state TimeLimit rate instead of a burst every 50 steps.
+A "step" is one env-step of every env of every rank (clip -> 40 control cycles of clamp / integrate / wall check / pair sweep ->
+observation, reward, done flags -> same-step auto-reset), i.e. what `VecBenchmarkPlanningEnv.step()` does, with the outputs written
+straight into a [T = 50, E, .] rollout buffer. Inputs (a ring of pre-generated random actions) are resident in HBM before the timed
+region. Episode phases are desynchronised before the warm-up (elapsed-step counters drawn uniformly from [0, 50)), so that even a
+short timed window sees the steady-state TimeLimit rate instead of a burst every 50 steps.
 
-Timed region: exactly K steps per block, R back-to-back blocks with R chosen (identically on every rank) so that the
-region lasts at least --min-seconds (0.1 s); barrier + synchronize on both sides, max over ranks. `value` = envs of all
-ranks x K x R / that time.
+Sub-batches (--sub-batches S, default 2): the rank's 65 536 envs are stepped as S contiguous sub-batches, each with its own handle and
+its own HIP stream, all S kernels launched by ONE C-ABI call per env-step (`gpr_step_many`). A step kernel lasts as long as its slowest
+wavefront while most SIMDs have run out of work; with S independent launches in flight the tail of one sub-batch overlaps with the
+bulk of another (measured, MI355X: S = 1 17.2 us per env-step of 65 536 envs, S = 2 13.7; more sub-batches need more than the 3.5 us of
+host time a launch costs and more hardware queues than the runtime's default four: S = 4 12.7 us with GPU_MAX_HW_QUEUES=8 in short bursts,
+host-bound in a sustained loop; a hipGraph of S kernel nodes costs 9.5 us per node to launch on ROCm 7.2 -- scratch/ubench/graphlaunch.hip).
+Closed-loop legal (every sub-batch is its own observation -> policy -> action -> step loop on its own stream) and bit
+for bit the results of the single launch (random streams are keyed by global env id). `config.single_launch` is the S = 1 number.
 
-For N > 1 the env batch is sharded (one process per GPU, contiguous env ranges, random streams keyed by global env id).
-`value` is WEAK scaling (65 536 envs per GPU); BASELINE.json's STRONG shape (65 536 envs in total) is timed in the same run and
-reported under config.strong_scaling. step() has no exchange step, so no timed region of an env-step rate holds a
-collective. Rollouts stay sharded (every rank's learner consumes its own [T, E/N, .] buffer); what crosses xGMI at a
-flush is ONE all_reduce of the six episode counters (48 bytes), timed as config.rollout_flush. Rank 0 prints one JSON line.
+Timed region: exactly K steps per block, R back-to-back blocks with R chosen (identically on every rank) so that the region lasts at
+least --min-seconds (0.1 s); barrier + synchronize on both sides, max over ranks. `value` = envs of all ranks x K x R / that time.
+HIP events are recorded on the streams the kernels are launched on.
 
-Workload (BASELINE.json): BenchmarkPlanningEnv, 4 movers, layout ones(6,6), reference defaults
-(num_cycles 40, dt 1e-3, v_max 2, a_max 10, circle r 0.11, std_noise 1e-5, TimeLimit 50), actions ~ U(-a_max, a_max).
-Extras in `config` (never `value`): sigma = 0; other batch sizes (4 096, 262 144 and 1 048 576 envs); the reference's dtype
-(f64 and f32 storage / f64 arithmetic); open-loop rollouts with 50 env-steps per launch (gpr_step_n) at 65 536 envs and at the
-8 192-envs-per-GPU shard of the strong-scaling shape.
+For N > 1 the env batch is sharded (one process per GPU, contiguous env ranges, random streams keyed by global env id). `value` is WEAK
+scaling (65 536 envs per GPU); BASELINE.json's STRONG shape (65 536 envs in total) is timed in the same run (`config.strong_scaling`).
+step() has no exchange step. What crosses xGMI is the rollout flush: `config.rollout_gather` times, at the strong shape, ONE
+`all_gather_into_tensor` of every rank's [50, E/N, .] rollout buffer (north_star's collective), the learner-minibatch gather and the
+48-byte counters all-reduce, each inside a timed region of env-steps. Rank 0 prints one JSON line.
+
+Workload (BASELINE.json): BenchmarkPlanningEnv, 4 movers, layout ones(6,6), reference defaults (num_cycles 40,
+dt 1e-3, v_max 2, a_max 10, circle r 0.11, std_noise 1e-5, TimeLimit 50), actions ~ U(-a_max, a_max).
 """
 from __future__ import annotations
 
@@ -36,6 +41,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,56 +49,117 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 T_ROLLOUT = 50
+NUM_SIMDS = 1024       # 256 CUs x 4 SIMDs
+SHADER_MHZ = 2400.0    # MI355X_MICROARCH.md
 
 
-def algorithmic_bytes_per_env_step(num_movers: int) -> int:
-    """fp32, learn_jerk=False: read action + pos + vel + goal (32 M) + step count (4); write pos + vel +
-    observation + achieved_goal + desired_goal (40 M) + reward (4) + terminated, truncated, 3 info flags (5) + step count (4)."""
-    return 72 * num_movers + 17
+def algorithmic_bytes_per_env_step(num_movers: int, precision: str = 'f32') -> int:
+    """learn_jerk=False: read action + pos + vel + goal (8 M values) + step count (4 B); write pos + vel + observation +
+    achieved_goal + desired_goal (10 M values) + reward (one value) + terminated, truncated, 3 info flags (5 B) + step count (4 B).
+    fp32 storage: 72 M + 17; f64 storage: 144 M + 21."""
+    v = 8 if precision == 'f64' else 4
+    return 18 * num_movers * v + v + 13
 
 
-def measured_traffic(num_envs: int, num_movers: int):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/round*_hbm_traffic.json: FETCH_SIZE
-    and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read
-    from inside this process; None when the profiled configuration is not the one being run."""
-    for name in ('round2_hbm_traffic.json', 'round1_hbm_traffic.json'):
+def kernel_name(precision: str, movers: int, tiles: int, shape: str = 'circle', noise: bool = True, multi: bool = False) -> str:
+    """the step kernel instance gpr_step launches for this configuration (gpr_env_kernels.hip: launch_one / launch_flags; layouts
+    ones(tiles, tiles) with the default radius are `layout_full`)"""
+    st, rt = {'f32': ('float', 'float'), 'f32_f64acc': ('float', 'double'), 'f64': ('double', 'double')}[precision]
+    lpe = 1
+    while lpe < movers:
+        lpe *= 2
+    full = 'true' if (rt == 'float' or shape == 'circle') else 'false'
+    return f'gpr::k_step{"_n" if multi else ""}<{st}, {rt}, {lpe}, false, {"true" if noise else "false"}, {full}, {0 if shape == "circle" else 1}>'
+
+
+def committed_profile(kind: str, kernel: str, envs_per_launch: int):
+    """what the committed rocprofv3 PMC passes hold for this kernel at this launch size (profiles/round*_{hbm_traffic,valu}.json: lists
+    of records keyed by kernel name and envs per launch). Counters cannot be read from inside this process; None when the profiled
+    configuration is not the one being run."""
+    for rnd in (3, 2, 1):
         try:
-            with open(os.path.join(ROOT, 'profiles', name)) as f:
+            with open(os.path.join(ROOT, 'profiles', f'round{rnd}_{kind}.json')) as f:
                 d = json.load(f)
-            if d['envs'] == num_envs and d['movers'] == num_movers:
-                return d['hbm_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
+        except (OSError, ValueError):
+            continue
+        for rec in (d if isinstance(d, list) else [d]):
+            if rec.get('kernel') == kernel and rec.get('envs') == envs_per_launch:
+                return dict(rec, source=f'profiles/round{rnd}_{kind}.json')
     return None
 
 
+def valu_block(kernel: str, envs_per_launch: int, kernel_us: float, in_flight: int, hbm_frac: float):
+    """the VALU figure next to the HBM fraction. From the committed PMC pass: vector instructions per wavefront and
+    SQ_ACTIVE_INST_VALU (quad-cycles summed over the SIMDs) of ONE launch; `in_flight` such launches share the machine for `kernel_us`
+    (live): busy = in_flight x ACTIVE_INST_VALU x 4 / (SIMDs x kernel clocks). `hbm_frac_at_full_issue` = the HBM fraction this
+    instruction stream would reach if the SIMDs issued it without a gap -- the ceiling the achieved fraction is to be read against."""
+    rec = committed_profile('valu', kernel, envs_per_launch)
+    if rec is None:
+        return None
+    busy = in_flight * rec['SQ_ACTIVE_INST_VALU'] * 4.0 / (NUM_SIMDS * kernel_us * SHADER_MHZ)
+    return {'insts_per_wavefront': rec['SQ_INSTS_VALU'] / rec['SQ_WAVES'], 'salu_insts_per_wavefront': rec['SQ_INSTS_SALU'] / rec['SQ_WAVES'],
+            'wavefronts_per_launch': rec['SQ_WAVES'], 'busy_frac': busy, 'hbm_frac_at_full_issue': hbm_frac / busy if busy > 0 else None,
+            'source': rec['source'],
+            'note': 'busy = launches_in_flight x SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel_us x 2.4 GHz); counters of one launch from the '
+                    'committed PMC pass, kernel time live'}
+
+
 # ----------------------------------------------------------------------------------------------------------------------
-# self-launch: `python bench.py --gpus N` with no launcher around it. Runs BEFORE anything touches the GPU (and never
-# re-execs): N child processes, one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is passed through.
+# self-launch: `python bench.py --gpus N` with no launcher around it. Runs BEFORE anything touches the GPU (and never re-execs): N
+# child processes, one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is passed through. The children are POLLED: the first one
+# that exits non-zero (or the overall timeout) ends the others -- a dead rank must not leave its peers in a collective for ever.
 # ----------------------------------------------------------------------------------------------------------------------
-def self_launch(n: int) -> int:
+def self_launch(n: int, timeout_s: float) -> int:
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode='w+')
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        # rank 0's stdout carries the JSON line; every rank's stderr goes to ours (a failing rank says why)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out or '').splitlines() if ln.startswith('{')]
-    if lines:
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t0, failed = time.monotonic(), None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f'rank {bad[0][0]} exited with code {bad[0][1]}'
+        elif all(c == 0 for c in codes):
+            break
+        elif time.monotonic() - t0 > timeout_s:
+            failed = f'no result within {timeout_s:.0f} s'
+        else:
+            time.sleep(0.1)
+    if failed is not None:
+        print(f'bench.py: {failed}; stopping the other ranks', file=sys.stderr, flush=True)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 5.0:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.startswith('{')]
+    if lines and failed is None:
         print(lines[-1], flush=True)
-    return max(abs(rc) for rc in rcs) if any(rcs) else (0 if lines else 1)
+        return 0
+    return 1
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 class Pass:
-    """One timed configuration on this rank."""
+    """One timed configuration on this rank: `envs` envs stepped as `sub` sub-batches (1: one handle, one launch per step)."""
 
-    def __init__(self, args, rank, local_rank, world, *, envs, std_noise=1e-5, precision=None, movers=None, tiles=None, flush=None):
+    def __init__(self, args, rank, local_rank, world, *, envs, std_noise=1e-5, precision=None, movers=None, tiles=None, flush=None, sub=1,
+                 collision_params=None):
         import numpy as np
         import torch
 
@@ -101,33 +168,46 @@ class Pass:
         self.args, self.rank, self.world = args, rank, world
         self.device = torch.device('cuda', local_rank)
         torch.cuda.set_device(self.device)
-        self.M, self.E = movers or args.movers, envs
+        self.M, self.E, self.S = movers or args.movers, envs, sub
         tiles = tiles or args.tiles
         precision = precision or args.precision
-        self.env = gpr.VecBenchmarkPlanningEnv(np.ones((tiles, tiles)), self.M, num_envs=envs, device=self.device, std_noise=std_noise,
-                                               precision=precision, env_id_offset=rank * envs)
+        kw = dict(num_envs=envs, device=self.device, std_noise=std_noise, precision=precision, env_id_offset=rank * envs, collision_params=collision_params)
+        if sub > 1:
+            self.env = gpr.VecBenchmarkPlanningEnvSubBatched(np.ones((tiles, tiles)), self.M, num_sub_batches=sub, **kw)
+            self.streams = self.env.streams
+        else:
+            self.env = gpr.VecBenchmarkPlanningEnv(np.ones((tiles, tiles)), self.M, **kw)
+            self.streams = [torch.cuda.current_stream(self.device)]
         env, M, E, T = self.env, self.M, self.E, T_ROLLOUT
         self.buf = gpr.distributed.RolloutBuffer(T, E, M, env.obs_dim, dtype=env.dtype, device=self.device)
-        self.outs = []
-        for t in range(T):
-            s = self.buf.slot(t)
-            self.outs.append(env.bind_outputs(s['observation'], s['achieved_goal'], s['desired_goal'], s['reward'], s['terminated'], s['truncated']))
         gen = torch.Generator(device=self.device).manual_seed(1234 + rank)
         ring = (torch.rand(T, E, 2 * M, device=self.device, generator=gen, dtype=torch.float32) * (2 * env.a_max) - env.a_max).to(env.dtype)
         self.buf['action'].copy_(ring)  # the rollout buffer's action field doubles as the action ring
-        self.actions = [self.buf['action'][t] for t in range(T)]
+        self.outs, self.actions = [], []
+        for t in range(T):
+            s = self.buf.slot(t)
+            self.outs.append(env.bind_outputs(observation=s['observation'], achieved_goal=s['achieved_goal'], desired_goal=s['desired_goal'],
+                                              reward=s['reward'], terminated=s['terminated'], truncated=s['truncated']))
+            self.actions.append(env.pack_actions(self.buf['action'][t]) if sub > 1 else self.buf['action'][t])
         env.reset(seed=0)
         # desynchronise the episode phases (TimeLimit counters), as a long-running job would be
-        env.elapsed_steps.copy_(torch.randint(0, T, (E,), device=self.device, generator=gen, dtype=torch.int32))
+        el = torch.randint(0, T, (E,), device=self.device, generator=gen, dtype=torch.int32)
+        if sub > 1:
+            for k, s in enumerate(env.subs):
+                s.elapsed_steps.copy_(el[env.sub_slice(k)])
+        else:
+            env.elapsed_steps.copy_(el)
+        torch.cuda.synchronize(self.device)
         self.flush = flush
         self.t = 0
         self.slots_written = 0
 
     def do_steps(self, n):
         env, acts, outs = self.env, self.actions, self.outs
+        step = env.step_all_into if self.S > 1 else env.step_into
         t = self.t
         for _ in range(n):
-            env.step_into(acts[t], outs[t])
+            step(acts[t], outs[t])
             t += 1
             if t == T_ROLLOUT:
                 if self.flush is not None:
@@ -145,23 +225,26 @@ class Pass:
             torch.cuda.synchronize(self.device)
 
     def run(self, steps, warmup, min_seconds):
-        """-> (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region, R). R starts at 1 and
-        grows (identically on every rank: it follows the all-reduced wall time) until the region lasts min_seconds."""
+        """-> (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region [the longest of the streams the
+        kernels ran on], R). R starts at 1 and grows (identically on every rank: it follows the all-reduced wall time) until the region
+        lasts min_seconds."""
         import torch
         reps = 1
         with torch.cuda.device(self.device):
             self.do_steps(warmup)
             for _ in range(6):
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.streams]
                 self.sync()
-                ev0.record()  # on the stream the kernels are launched on (torch's current stream is what step_into passes down)
+                for (e0, _), st in zip(ev, self.streams):
+                    e0.record(st)  # on the stream the kernels are launched on
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     self.do_steps(steps)
-                ev1.record()
+                for (_, e1), st in zip(ev, self.streams):
+                    e1.record(st)
                 self.sync()
                 wall = time.perf_counter() - t0
-                gpu_ms = ev0.elapsed_time(ev1)
+                gpu_ms = max(e0.elapsed_time(e1) for e0, e1 in ev)
                 if self.world > 1:
                     import torch.distributed as dist
                     w = torch.tensor([wall], device=self.device, dtype=torch.float64)
@@ -189,7 +272,10 @@ def timed(args, rank, local_rank, world, steps=None, warmup=None, **kw):
     p = Pass(args, rank, local_rank, world, **kw)
     wall, gpu_ms, reps = p.run(steps or args.steps, args.warmup if warmup is None else warmup, args.min_seconds)
     n = (steps or args.steps) * reps
-    res = {'wall': wall, 'gpu_ms': gpu_ms, 'reps': reps, 'n_steps': n, 'kernel_us': gpu_ms * 1e3 / n,
+    # step_us: HIP-event time per env-step of the rank. Every stream runs its n launches back to back, so this is also the average
+    # duration of ONE launch as a kernel trace shows it -- S of them (one per sub-batch) in flight at any time
+    res = {'wall': wall, 'gpu_ms': gpu_ms, 'reps': reps, 'n_steps': n, 'step_us': gpu_ms * 1e3 / n,
+           'sub_batches': p.S, 'envs_per_launch': p.E // p.S,
            'env_steps_per_s': world * p.E * n / wall, 'done_fraction': p.done_fraction(), 'rollout_bytes': p.buf.nbytes}
     p.close()
     return res
@@ -241,8 +327,8 @@ def timed_rollout_launch(args, rank, local_rank, world, envs, n_steps=T_ROLLOUT)
     n = launches * n_steps
     us = wall / n * 1e6
     return {'what': f'gpr_step_n: {n_steps} env-steps per kernel launch (open-loop actions; outputs identical to {n_steps} step() calls)',
-            'kernel': 'gpr::k_step_n<float, float, 4, false, true, true, 0>', 'envs_per_gpu': envs, 'env_steps_per_s': world * envs * n / wall,
-            'us_per_step': us, 'hbm_frac': algorithmic_bytes_per_env_step(args.movers) * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            'kernel': kernel_name(args.precision, args.movers, args.tiles, multi=True), 'envs_per_gpu': envs, 'env_steps_per_s': world * envs * n / wall,
+            'us_per_step': us, 'hbm_frac': algorithmic_bytes_per_env_step(args.movers, args.precision) * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def cpu_baseline(args):
@@ -268,6 +354,24 @@ def cpu_baseline(args):
             'sample': f'{E} envs x {n} steps ({dt:.1f} s), oracle/gpr_oracle.c (fp64, reference-literal loops), {threads} pthreads'}
 
 
+def roofline_of(r, precision, movers, tiles, envs):
+    """the roofline block of one timed pass. With S sub-batches the rank has S launches in flight, one per stream, each stream's launches
+    back to back: `kernel_us` = a stream's HIP-event time / its launches = what a kernel trace shows as the average duration of one launch,
+    and achieved = S x algorithmic bytes per launch / kernel_us (= the bytes of one env-step of all the rank's envs / the time it takes)."""
+    B = algorithmic_bytes_per_env_step(movers, precision)
+    S, epl = r['sub_batches'], r['envs_per_launch']
+    kernel_us = r['step_us']
+    achieved = S * B * epl / (kernel_us * 1e-6) / 1e9
+    name = kernel_name(precision, movers, tiles)
+    tr = committed_profile('hbm_traffic', name, epl)
+    frac = achieved / HBM_PEAK_GBS
+    return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': frac,
+            'traffic': tr['hbm_bytes_per_launch'] if tr else None, 'kernel': name, 'kernel_us': kernel_us, 'launches_in_flight': S,
+            'envs_per_launch': epl, 'algorithmic_bytes_per_env_step': B, 'algorithmic_bytes_per_launch': B * epl,
+            'achieved_is': 'launches_in_flight x algorithmic_bytes_per_launch / kernel_us',
+            'valu': valu_block(name, epl, kernel_us, S, frac)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -277,18 +381,25 @@ def main():
     ap.add_argument('--movers', type=int, default=4)
     ap.add_argument('--tiles', type=int, default=6)
     ap.add_argument('--precision', default='f32', choices=['f32', 'f32_f64acc', 'f64'])
+    ap.add_argument('--sub-batches', type=int, default=2, help='sub-batches (handles + HIP streams) the rank\'s envs are stepped as; 1 = one launch per step')
     ap.add_argument('--min-seconds', type=float, default=0.1, help='minimum length of every timed region (blocks of --steps are repeated)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline pass only (profiling runs)')
-    ap.add_argument('--rollout-gather', action='store_true', help='also time a full all-gather of the rollout buffers at every flush (N > 1)')
-    ap.add_argument('--gather-timeout', type=float, default=240.0, help='seconds the optional rollout all-gather pass may take')
+    ap.add_argument('--no-rollout-gather', action='store_true', help='N > 1: skip the timed rollout all-gather passes')
+    ap.add_argument('--rollout-gather', action='store_true', help='(accepted for compatibility: the gather passes are on by default for N > 1)')
+    ap.add_argument('--gather-timeout', type=float, default=240.0, help='seconds the rollout all-gather passes may take before the line is printed without them')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launch: seconds before the ranks are stopped')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' + --single-device rehearses N > 1 on one GPU")
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
+    ap.add_argument('--fail-rank', type=int, default=-1, help='test hook: this rank exits with code 7 before the rendezvous')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(self_launch(args.gpus))  # nothing has touched the GPU in this process
+        sys.exit(self_launch(args.gpus, args.launch_timeout))  # nothing has touched the GPU in this process
+    if args.fail_rank >= 0 and int(os.environ.get('RANK', '0')) == args.fail_rank:
+        print(f'bench.py: rank {args.fail_rank} failing on request (--fail-rank)', file=sys.stderr, flush=True)
+        sys.exit(7)
 
     import gymnasium_planar_robotics_amd as gpr
 
@@ -297,88 +408,122 @@ def main():
     rank, local_rank, world = gpr.distributed.init_from_env(args.backend)
     if world != args.gpus and rank == 0:
         print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running on {world} ranks', file=sys.stderr)
+    backend = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = {'backend': dist.get_backend(), 'world_size_seen_by_backend': dist.get_world_size()}
 
-    E, M, K = args.envs_per_gpu, args.movers, args.steps
-    head = timed(args, rank, local_rank, world, envs=E)                    # headline: the reference's default noise
-    B = algorithmic_bytes_per_env_step(M)
-    kernel_s = head['kernel_us'] * 1e-6  # HIP events around the timed region / launches: average duration of the step kernel
-    achieved = B * E / kernel_s / 1e9
+    E, M, K, S = args.envs_per_gpu, args.movers, args.steps, max(1, args.sub_batches)
+    while E % S:
+        S //= 2
+    head = timed(args, rank, local_rank, world, envs=E, sub=S)                    # headline: the reference's default noise
     cfg = {
         'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
                     'std_noise 1e-5 (reference default), TimeLimit 50 with desynchronised episode phases, same-step auto-reset, '
                     'actions ~ U(-10, 10)',
         'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
+        'sub_batches': f'{S} sub-batches of {E // S} envs per GPU, one handle + one HIP stream each, {S} launches per env-step issued by one gpr_step_many call',
         'timed_steps': head['n_steps'], 'timed_blocks': head['reps'], 'timed_seconds': head['wall'],
         'done_fraction_per_step': head['done_fraction'],
     }
+    if backend:
+        cfg['distributed'] = backend
     line = {
         'metric': 'env-steps/sec, BenchmarkPlanningEnv 4 movers @ 65536 envs per MI355X',
         'value': head['env_steps_per_s'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
         'ms_per_step': head['wall'] / head['n_steps'] * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {'f32': 'f32', 'f32_f64acc': 'f32 storage / f64 arithmetic', 'f64': 'f64'}[args.precision], 'data': 'synthetic',
         'config': cfg,
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': measured_traffic(E, M), 'kernel': 'gpr::k_step<float, float, 4, false, true, true, 0>',
-                     'kernel_us': head['kernel_us'], 'algorithmic_bytes_per_env_step': B},
+        'roofline': roofline_of(head, args.precision, M, args.tiles, E),
     }
 
     if not args.no_extras:
-        s0 = timed(args, rank, local_rank, world, envs=E, std_noise=0.0)
+        if S > 1:
+            one = timed(args, rank, local_rank, world, envs=E, sub=1)
+            cfg['single_launch'] = {'what': 'the same env-steps as ONE launch per step (one handle, one stream): the kernel lasts as long as its slowest wavefront',
+                                    'env_steps_per_s': one['env_steps_per_s'], 'roofline': roofline_of(one, args.precision, M, args.tiles, E)}
+        s0 = timed(args, rank, local_rank, world, envs=E, std_noise=0.0, sub=S)
         cfg['sigma0_env_steps_per_s'] = s0['env_steps_per_s']
-        cfg['sigma0_kernel_us'] = s0['kernel_us']
+        cfg['sigma0_step_us'] = s0['step_us']
         if world > 1:
             # BASELINE.json's strong-scaling shape: 65 536 envs in total
             Es = max(1, args.envs_per_gpu // world)
-            st = timed(args, rank, local_rank, world, envs=Es)
-            cfg['strong_scaling'] = {'envs_total': Es * world, 'envs_per_gpu': Es, 'env_steps_per_s': st['env_steps_per_s'],
-                                     'ms_per_step': st['wall'] / st['n_steps'] * 1e3, 'kernel_us': st['kernel_us'],
+            Ss = S
+            while Es % Ss:
+                Ss //= 2
+            st = timed(args, rank, local_rank, world, envs=Es, sub=Ss)
+            cfg['strong_scaling'] = {'envs_total': Es * world, 'envs_per_gpu': Es, 'sub_batches': Ss, 'env_steps_per_s': st['env_steps_per_s'],
+                                     'ms_per_step': st['wall'] / st['n_steps'] * 1e3, 'step_us': st['step_us'],
                                      'rollout_launch': timed_rollout_launch(args, rank, local_rank, world, Es)}
-
-            def flush_counters(p):
-                p.env.all_reduce_episode_counters()  # ONE all_reduce of six uint64 counters; rollouts stay sharded
-
-            fl = timed(args, rank, local_rank, world, envs=E, flush=flush_counters)
-            cfg['rollout_flush'] = {
-                'what': 'rollouts stay sharded (each rank\'s learner reads its own [50, E, .] buffer); every 50 steps ONE all_reduce '
-                        'of the six on-device episode counters (48 B) inside the timed region',
-                'env_steps_per_s': fl['env_steps_per_s'], 'rollout_bytes_per_rank_per_flush': fl['rollout_bytes']}
         else:
             sizes = {}
             for n in (4096, 262144, 1048576):
-                r = timed(args, rank, local_rank, world, envs=n, steps=max(50, K * E // max(n, E) // 2), warmup=min(args.warmup, 60))
-                sizes[str(n)] = {'env_steps_per_s': r['env_steps_per_s'], 'kernel_us': r['kernel_us'],
-                                 'hbm_frac': B * n / (r['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                r = timed(args, rank, local_rank, world, envs=n, steps=max(50, K * E // max(n, E) // 2), warmup=min(args.warmup, 60), sub=S)
+                sizes[str(n)] = {'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us'], 'sub_batches': S,
+                                 'hbm_frac': algorithmic_bytes_per_env_step(M, args.precision) * n / (r['step_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
             cfg['other_batch_sizes'] = sizes
             cfg['rollout_launch'] = {str(n): timed_rollout_launch(args, rank, local_rank, world, n) for n in (8192, E)}
             if args.precision == 'f32':
-                prec = {}
-                for pr in ('f32_f64acc', 'f64'):
-                    r = timed(args, rank, local_rank, world, envs=E, precision=pr, steps=max(50, K // 4), warmup=min(args.warmup, 60))
-                    bytes_pr = B if pr == 'f32_f64acc' else 2 * (72 * M) + 17
-                    prec[pr] = {'env_steps_per_s': r['env_steps_per_s'], 'kernel_us': r['kernel_us'],
-                                'hbm_frac': bytes_pr * E / (r['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
-                cfg['reference_dtype'] = prec
+                # the reference's own arithmetic (float64): its own roofline block, kernel name and bytes
+                ref = {}
+                for pr in ('f64', 'f32_f64acc'):
+                    r = timed(args, rank, local_rank, world, envs=E, precision=pr, steps=max(50, K // 4), warmup=min(args.warmup, 60), sub=S)
+                    ref[pr] = dict(roofline_of(r, pr, M, args.tiles, E), env_steps_per_s=r['env_steps_per_s'])
+                line['roofline_reference_dtype'] = ref['f64']
+                cfg['reference_dtype'] = {k: {'env_steps_per_s': v['env_steps_per_s'], 'step_us': v['kernel_us'], 'hbm_frac': v['frac'],
+                                              'kernel': v['kernel']} for k, v in ref.items()}
 
-    if world > 1 and args.rollout_gather:
-        # optional: + a full all-gather of every rank's rollout buffer per flush (GBs over xGMI; bound by the links, not by
-        # the env engine -- DESIGN.md section 4). A watchdog makes sure the headline is printed if the collective hangs, and
-        # that the hang is NOT reported as success.
+    if world > 1 and not args.no_rollout_gather:
+        # north_star / SURVEY 8(e): "a single RCCL gather of rollout tensors at buffer flush", timed at the strong shape (65 536 envs in
+        # total: [50, E/N, .] per rank = 56 MB at N = 8) inside a timed region of env-steps. A watchdog makes sure the headline is
+        # printed if a collective hangs, and that the hang is NOT reported as success.
         import threading
 
         def give_up():
             if rank == 0:
-                cfg['rollout_gather'] = {'status': f'no result within {args.gather_timeout:.0f} s'}
+                cfg.setdefault('rollout_gather', {})['status'] = f'no result within {args.gather_timeout:.0f} s'
                 print(json.dumps(line), flush=True)
             os._exit(3)
 
         dog = threading.Timer(args.gather_timeout, give_up)
         dog.daemon = True
         dog.start()
-        g = timed(args, rank, local_rank, world, envs=E, flush=lambda p: p.buf.flush())
+        Es = max(1, args.envs_per_gpu // world)
+        Ss = S
+        while Es % Ss:
+            Ss //= 2
+
+        def fenced(p, fn):  # the collective runs on torch's current stream: behind the sub-batches' kernels, ahead of their next ones
+            if p.S > 1:
+                p.env.synchronize()
+            fn()
+            if p.S > 1:
+                p.env.wait_for_caller()
+
+        def flush_all(p):
+            fenced(p, p.buf.flush)  # ONE all_gather_into_tensor of the rank's whole [50, E/N, .] buffer
+
+        def flush_minibatch(p):
+            fenced(p, lambda: p.buf.gather_minibatch(min(1024, p.E)))  # ONE all-gather of a learner-sized [50, 1024, .] slice
+
+        def flush_counters(p):
+            p.env.all_reduce_episode_counters()  # ONE all_reduce of six uint64 counters; rollouts stay sharded
+
+        base = timed(args, rank, local_rank, world, envs=Es, sub=Ss, steps=max(100, K // 4))
+        g = timed(args, rank, local_rank, world, envs=Es, sub=Ss, steps=max(100, K // 4), flush=flush_all)
+        mb = timed(args, rank, local_rank, world, envs=Es, sub=Ss, steps=max(100, K // 4), flush=flush_minibatch)
+        fc = timed(args, rank, local_rank, world, envs=Es, sub=Ss, steps=max(100, K // 4), flush=flush_counters)
         dog.cancel()
+        per_flush = lambda r: (r['wall'] / r['n_steps'] - base['wall'] / base['n_steps']) * T_ROLLOUT * 1e3  # noqa: E731
         cfg['rollout_gather'] = {
-            'what': 'ONE all_gather_into_tensor of every rank\'s [50, E, .] rollout buffer per 50 steps inside the timed region',
-            'env_steps_per_s': g['env_steps_per_s'], 'bytes_per_rank_per_flush': g['rollout_bytes']}
+            'what': f'at the strong shape ({Es} envs per GPU, {world} ranks), every {T_ROLLOUT} env-steps inside the timed region: ONE all_gather_into_tensor of '
+                    'every rank\'s [50, E/N, .] rollout buffer; or ONE all-gather of a [50, 1024, .] learner minibatch; or ONE all_reduce of the six '
+                    'episode counters (48 B)',
+            'status': 'ok', 'bytes_per_rank_per_flush': g['rollout_bytes'],
+            'env_steps_per_s': g['env_steps_per_s'], 'ms_per_flush': per_flush(g),
+            'no_flush_env_steps_per_s': base['env_steps_per_s'],
+            'minibatch': {'env_steps_per_s': mb['env_steps_per_s'], 'ms_per_flush': per_flush(mb)},
+            'counters_only': {'env_steps_per_s': fc['env_steps_per_s'], 'ms_per_flush': per_flush(fc)}}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

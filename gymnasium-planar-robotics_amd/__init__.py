@@ -8,8 +8,9 @@ from .envs.basic_envs import VecBasicPlanarRoboticsEnv
 from .envs.manipulation.benchmark_pushing_env import VecBenchmarkPushingEnv
 from .envs.planning.benchmark_planning_env import VecBenchmarkPlanningEnv
 from .envs.planning.parallel_planning_env import VecBenchmarkPlanningParallelEnv
+from .envs.planning.sub_batched_env import VecBenchmarkPlanningEnvSubBatched
 from .utils import geometry_2D_utils
 
 registered_ids = registration.register_gymnasium_envs()  # [] unless gymnasium is importable
 
-__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'VecBenchmarkPlanningParallelEnv', 'VecBenchmarkPushingEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']
+__all__ = ['VecBasicPlanarRoboticsEnv', 'VecBenchmarkPlanningEnv', 'VecBenchmarkPlanningParallelEnv', 'VecBenchmarkPlanningEnvSubBatched', 'VecBenchmarkPushingEnv', 'distributed', 'geometry_2D_utils', 'spaces', '_native']

@@ -537,6 +537,22 @@ int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void
     return rc;
 }
 
+int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_dev, const gpr_step_out *const *outs, void *const *hip_streams) {
+    if (n < 1 || !envs || !actions_dev || !outs || !hip_streams) return fail(nullptr, GPR_E_INVALID, "gpr_step_many: bad argument");
+    for (int32_t i = 0; i < n; ++i) {  // validate everything before anything is launched
+        if (!envs[i]) return fail(nullptr, GPR_E_INVALID, "gpr_step_many: NULL handle");
+        if (!envs[i]->bound) return fail(envs[i], GPR_E_UNBOUND, "gpr_step_many: call gpr_bind_state first");
+        if (!actions_dev[i]) return fail(envs[i], GPR_E_INVALID, "gpr_step_many: action is NULL");
+        const int rc = check_out(envs[i], outs[i]);
+        if (rc != GPR_OK) return rc;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        const int rc = gpr_step(envs[i], actions_dev[i], outs[i], hip_streams[i]);
+        if (rc != GPR_OK) return rc;
+    }
+    return GPR_OK;
+}
+
 int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_step_out *out, void *hip_stream) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_step_n: NULL handle");
     if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_step_n: call gpr_bind_state first");

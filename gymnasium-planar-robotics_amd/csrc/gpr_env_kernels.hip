@@ -158,7 +158,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         used += taken;
     }
     if (SCRIPT && scripted) {
-        if ((P.cand_used != nullptr) & live & need & (mv == 0)) P.cand_used[env_global - P.env_id_offset] = used;
+        if ((P.cand_used != nullptr) & live & need & (mv == 0)) P.cand_used[env_global - P.env_id_offset] = used < P.n_cand ? used : P.n_cand;  // (a loop that found the stream empty took nothing)
     }
 
     // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads

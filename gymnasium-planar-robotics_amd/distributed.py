@@ -60,6 +60,17 @@ def make_sharded(env_cls, *args, num_envs_global: int, rank: int | None = None, 
     return env_cls(*args, num_envs=stop - start, env_id_offset=start, **kwargs)
 
 
+def _all_gather_bytes(recv: torch.Tensor, send: torch.Tensor) -> None:
+    """ONE all_gather_into_tensor; RCCL ("nccl") moves device memory directly, the gloo rehearsal backend goes through the host"""
+    if dist.get_backend() == 'gloo' and send.is_cuda:
+        h_send = send.cpu()
+        h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(h_recv, h_send)
+        recv.copy_(h_recv)
+    else:
+        dist.all_gather_into_tensor(recv, send)
+
+
 @dataclass
 class _Field:
     name: str
@@ -148,7 +159,7 @@ class RolloutBuffer:
         world = 1
         if dist.is_initialized() and dist.get_world_size() > 1:
             world = dist.get_world_size()
-            dist.all_gather_into_tensor(recv, send)
+            _all_gather_bytes(recv, send)
         else:
             recv.copy_(send)
         g = recv.view(world, offs[-1])
@@ -166,6 +177,6 @@ class RolloutBuffer:
         world = dist.get_world_size()
         if self._gathered is None:
             self._gathered = torch.empty(world * self.nbytes, dtype=torch.uint8, device=self.device)
-        dist.all_gather_into_tensor(self._gathered, self.storage)
+        _all_gather_bytes(self._gathered, self.storage)
         g = self._gathered.view(world, self.nbytes)
         return {f.name: self._view(g, f, lead=(world,)) for f in self.fields}

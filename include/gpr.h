@@ -126,6 +126,13 @@ int gpr_reset_candidates(gpr_env *env, const uint8_t *mask_dev, int32_t n_cand, 
 /* step(action) (BE:1835-1950 + PL:420-450 + TimeLimit). action_dev: [E][2M] real, clipped to the action space. */
 int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void *hip_stream);
 
+/* gpr_step on n handles in ONE call: handle i steps with actions_dev[i] into outs[i] on hip_streams[i]. For an env batch that is
+ * stepped as several sub-batches, each with its own handle (contiguous env range, env_id_offset) and its own HIP stream, so that the
+ * slow wavefronts at the end of one sub-batch's kernel overlap with the bulk of another's ("sub-batches"): the
+ * host pays the call overhead once per env-step instead of once per sub-batch. Everything is validated before the first launch. */
+int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_dev, const gpr_step_out *const *outs,
+                  void *const *hip_streams);
+
 /* n_steps env-steps in ONE launch, for open-loop rollouts (random / scripted / replayed actions; the benchmark's rollouts): what
  * n_steps calls of gpr_step do, bit for bit (step i draws from call counter tick + i), without a launch, a grid-wide drain and a
  * whole-batch load burst between two steps. action_dev is [n_steps][E][2M] real; EVERY tensor of `out` (final_* included, if set)

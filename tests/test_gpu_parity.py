@@ -672,8 +672,71 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     c = line['config']
     assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 2048
     assert c['strong_scaling']['rollout_launch']['env_steps_per_s'] > 0
-    assert c['rollout_flush']['env_steps_per_s'] > 0 and 0 < c['done_fraction_per_step'] < 0.5
+    assert 0 < c['done_fraction_per_step'] < 0.5
     assert c['timed_seconds'] >= 0.02 and c['timed_steps'] % 30 == 0
+    # north_star's collective is in the DEFAULT line: one all-gather of the [50, E/N, .] rollout buffers per flush, timed
+    g = c['rollout_gather']
+    assert g['status'] == 'ok' and g['env_steps_per_s'] > 0 and g['minibatch']['env_steps_per_s'] > 0 and g['counters_only']['env_steps_per_s'] > 0
+    assert g['bytes_per_rank_per_flush'] > 50 * 2048 * 100
+    assert c['distributed'] == {'backend': 'gloo', 'world_size_seen_by_backend': 2}
+    assert line['roofline']['launches_in_flight'] == 2 and line['roofline']['envs_per_launch'] == 2048
+    assert line['roofline']['kernel'] == 'gpr::k_step<float, float, 4, false, true, true, 0>'
+
+
+def test_bench_dead_rank_fails_fast(gpr):
+    """a rank that dies before the rendezvous must not leave its peer waiting: the self-launcher polls its children, stops the others
+    and returns non-zero within seconds, without a JSON line"""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device', '--envs-per-gpu', '1024',
+                        '--steps', '10', '--warmup', '2', '--no-cpu-baseline', '--fail-rank', '1'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.monotonic() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert 'rank 1' in r.stderr
+
+
+@pytest.mark.parametrize('K,kw', [(2, {}), (4, {'precision': 'f64'}), (4, {'autoreset_mode': 'next_step'})])
+def test_sub_batches_equal_the_whole_batch(gpr, K, kw):
+    """VecBenchmarkPlanningEnvSubBatched (K handles over contiguous env ranges, K streams) returns bit for bit what one handle over the
+    whole batch returns -- through step() (events), and through step_all_into (one gpr_step_many call, outputs bound into slices)"""
+    E, M, T = 4096, 4, 60
+    lay = np.ones((6, 6))
+    whole = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E, **kw)
+    parts = gpr.VecBenchmarkPlanningEnvSubBatched(lay, M, num_envs=E, num_sub_batches=K, **kw)
+    ow, _ = whole.reset(seed=5); op, _ = parts.reset(seed=5)
+    for k in ow:
+        assert torch.equal(ow[k], op[k]), k
+    g = torch.Generator(device='cuda').manual_seed(1)
+    acts = (torch.rand(T, E, 2 * M, device='cuda', generator=g) * 20 - 10).to(whole.dtype)
+    n_done = 0
+    for t in range(T // 2):
+        a = whole.step(acts[t]); b = parts.step(acts[t])
+        for k in a[0]:
+            assert torch.equal(a[0][k], b[0][k]), (t, k)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for k in ('is_success', 'mover_collision', 'wall_collision'):
+            assert torch.equal(a[4][k], b[4][k]), (t, k)
+        n_done += int((a[2] | a[3]).sum())
+    assert n_done > E // 4
+    # the bench's path: one C-ABI call per env-step, outputs land in slices of [E, .] tensors, no events
+    z = lambda *s, dtype=whole.dtype: torch.zeros(*s, dtype=dtype, device='cuda')  # noqa: E731
+    outs = dict(observation=z(E, whole.obs_dim), achieved_goal=z(E, 2 * M), desired_goal=z(E, 2 * M), reward=z(E), terminated=z(E, dtype=torch.uint8),
+                truncated=z(E, dtype=torch.uint8))
+    bound = parts.bind_outputs(**outs)
+    torch.cuda.synchronize()
+    for t in range(T // 2, T):
+        a = whole.step(acts[t])
+        parts.step_all_into(parts.pack_actions(acts[t]), bound)
+        parts.synchronize()
+        for k in a[0]:
+            assert torch.equal(a[0][k], outs[k]), (t, k)
+        assert torch.equal(a[1], outs['reward']) and torch.equal(a[2], outs['terminated'].bool()) and torch.equal(a[3], outs['truncated'].bool())
+    for k in range(K):
+        sl = parts.sub_slice(k)
+        assert torch.equal(whole.pos[sl], parts.sub(k).pos) and torch.equal(whole.goals[sl], parts.sub(k).goals) and torch.equal(whole.elapsed_steps[sl], parts.sub(k).elapsed_steps)
+    whole.close(); parts.close()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
