@@ -474,16 +474,24 @@ int gpr_set_rng_state(gpr_env *env, uint64_t seed, uint64_t tick) {
 int gpr_enable_counters(gpr_env *env, int32_t enable) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_enable_counters: NULL handle");
     if (const int rc = check_device(env, "gpr_enable_counters")) return rc;
-    if (enable && !env->counters) {
+    if (enable) {
         // one row per wavefront of the step kernels' GRID -- whole blocks: the wavefronts of the last block that hold no env still
-        // read and write their (zero) rows. Planning: lpe lanes per env; pushing: PUSH_LANES lanes per env -- whichever is more.
-        const int64_t lanes = std::max<int64_t>(env->lpe, PUSH_LANES);
-        env->counter_rows = (size_t)((env->cfg.num_envs * lanes + BLOCK - 1) / BLOCK) * (size_t)(BLOCK / 64);
-        const size_t bytes = env->counter_rows * GPR_NUM_COUNTERS * sizeof(uint32_t);
-        hipError_t he = hipMalloc(reinterpret_cast<void **>(&env->counters), bytes);
-        if (he != hipSuccess) { env->counters = nullptr; return fail_hip(env, he, "gpr_enable_counters: hipMalloc"); }
-        he = hipMemset(env->counters, 0, bytes);
-        if (he != hipSuccess) return fail_hip(env, he, "gpr_enable_counters: hipMemset");
+        // read and write their (zero) rows. Planning: lpe lanes per env; pushing: up to PUSH_LANES lanes per env (k_push).
+        const int64_t lanes = env->push_ready ? std::max<int64_t>(env->lpe, PUSH_LANES) : env->lpe;
+        const size_t rows = (size_t)((env->cfg.num_envs * lanes + BLOCK - 1) / BLOCK) * (size_t)(BLOCK / 64);
+        if (env->counters && rows > env->counter_rows) {  // (gpr_push_configure came after the table was made: a larger one, counts restart)
+            (void)hipDeviceSynchronize();
+            (void)hipFree(env->counters);
+            env->counters = nullptr;
+        }
+        if (!env->counters) {
+            env->counter_rows = rows;
+            const size_t bytes = env->counter_rows * GPR_NUM_COUNTERS * sizeof(uint32_t);
+            hipError_t he = hipMalloc(reinterpret_cast<void **>(&env->counters), bytes);
+            if (he != hipSuccess) { env->counters = nullptr; return fail_hip(env, he, "gpr_enable_counters: hipMalloc"); }
+            he = hipMemset(env->counters, 0, bytes);
+            if (he != hipSuccess) return fail_hip(env, he, "gpr_enable_counters: hipMemset");
+        }
     }
     env->counters_on = enable != 0;
     return GPR_OK;
@@ -659,8 +667,9 @@ int gpr_push_configure(gpr_env *env, const gpr_push_params *pp, const gpr_push_s
     if (!st->mover_rot_dev || !st->object_dev) return fail(env, GPR_E_INVALID, "gpr_push_configure: state pointers must be set");
     fill_push<float>(*env, *pp, env->push_f);
     fill_push<double>(*env, *pp, env->push_d);
-    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev, nullptr, nullptr, nullptr, nullptr, 0};
+    env->push_ptrs = PushPtrs{st->mover_rot_dev, st->object_dev, nullptr, nullptr, nullptr, nullptr, 0, 0};
     env->push_ready = true;
+    if (env->counters && env->counters_on) return gpr_enable_counters(env, 1);  // (the pushing grid is wider than the table was made for)
     return GPR_OK;
 }
 

@@ -20,7 +20,7 @@ constexpr uint32_t KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 
 #ifndef GPR_BLOCK
 #define GPR_BLOCK 256
 #endif
-constexpr int PUSH_LANES = 1;  // lanes per env of the pushing kernels (gpr_push_kernels.hip)
+constexpr int PUSH_LANES = 64;  // most lanes per env the pushing kernels use (gpr_push_kernels.hip: launch_push3)
 constexpr int BLOCK = GPR_BLOCK;  // threads per block of the step / reset / push kernels (a build-time experiment knob)
 
 // Scalar constants in the compute type. The host fills a float and a double copy so that a kernel reads its constants
@@ -84,6 +84,7 @@ struct PushPtrs {
     const void *cand;                   // gpr_push_reset_candidates: the object's start candidates [n_cand][E][2] (PU:403-405), nullable
     int32_t *cand_used;                 // [E] nullable: candidates consumed
     int32_t n_cand;
+    int32_t lane_shift;                 // log2(lanes per env) of this launch (see k_push: small batches spread over more wavefronts)
 };
 template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
 template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }

@@ -1,5 +1,17 @@
-// gpr_push_kernels.hip -- fused BenchmarkPushingEnv step / reset kernels: one lane per env, NM = 1 (the reference's env, PU:196)
-// or 2 movers (BASELINE.json's config 3; engine-defined) + 1 pushed object.
+// gpr_push_kernels.hip -- fused BenchmarkPushingEnv step / reset kernels: NM = 1 (the reference's env, PU:196) or 2 movers
+// (BASELINE.json's config 3; engine-defined) + 1 pushed object.
+//
+// LANES PER ENV. With one lane per env a batch of 4 096 envs is 64 wavefronts on 1 024 SIMDs, and every wavefront walks through the
+// whole contact path in practically every cycle (27 % of the envs are within reach of the object at any time, 4 % touch: of 64 envs
+// some env always is). So a launch gives every env 2^lane_shift adjacent lanes -- as many as keep the grid within ONE wavefront per
+// SIMD (launch_push3: 16 lanes per env at 4 096 envs, 4 at 16 384, 1 from 65 536 on). All lanes of an env's group run the env
+// redundantly (same loads, same arithmetic, same votes: nothing to exchange, results bit-identical to one lane per env); the group's
+// first lane stores. A wavefront then holds 4-16 envs instead of 64 and its wave-level decisions "is any env within reach / touching"
+// fail more often. Measured (scratch/pushlanes.py, MI355X, us per step): 4 096 envs x 2 movers 147 -> 128, x 1 mover 63.8 -> 61.6; f64
+// 393 -> 348 / 207 -> 197. What it does NOT buy is a shorter kernel than its slowest env: an env that pushes the object through all 40
+// cycles runs the full contact path 40 times whatever shares its wavefront, and that dependent chain (~600 instructions per cycle at
+// ~6 clocks each for a lone wavefront) is the kernel's duration at every batch size up to one wavefront per SIMD. More wavefronts per
+// SIMD do not hide it, they share the SIMD: 2 per SIMD +30 %, 4 per SIMD +85 % (same script).
 //
 // Pinned by the reference: control + clamp (PU:419-448), wall check (BE:426-788), obs / info / reward / terminated (PU:457-607),
 // reset sampling (PU:373-417). The contact physics is the engine's own planar model "gpr-push-v2" (parity unpinned: the
@@ -11,6 +23,8 @@
 // arrays (written through unrolled selects, never indexed dynamically -- the first version kept them in scratch memory and
 // spent its time waiting for it), their effective masses are inverted once per cycle, and the contact block of a pair is
 // entered only by wavefronts in which some env's circumscribed circles overlap.
+#include <cstdlib>
+
 #include "gpr.h"
 #include "gpr_device.h"
 #include "gpr_host.h"
@@ -433,8 +447,8 @@ template <typename RT> __device__ __forceinline__ bool pair_hit2(const Cst<RT> &
 // 'mover_start_xy_pos' [E][2 NM] / 'object_goal_xy_pos' [E][2] (NULL: sampled).
 template <typename ST, typename RT, int NM, bool NOISE, bool FULL>
 __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, const PushCst<RT> &Q, const PushPtrs &X, const Tables<RT> &T, int64_t e,
-                                                          int64_t env_global, RT c, bool need, R2<RT> (&p)[NM], R2<RT> &g, RT &ox, RT &oy, bool &wc,
-                                                          bool &mc) {
+                                                          int64_t env_global, RT c, bool need, bool lead, R2<RT> (&p)[NM], R2<RT> &g, RT &ox, RT &oy,
+                                                          bool &wc, bool &mc) {
     const Cst<RT> &C = cst<RT>(P);
     uint32_t ks[NM], kn[NM];
 #pragma unroll
@@ -509,7 +523,8 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
         candidate(ks[0], e, trial, cx, cy);
         if (pending) { ox = cx; oy = cy; pending = !far_enough(cx, cy, p); n_tried = trial + 1; }
     }
-    for (unsigned long long pm = __ballot(pending); pm != 0ull; pm &= pm - 1ull) {
+    const int gsh = X.lane_shift < 6 ? X.lane_shift : 6;  // lanes of a group inside this wavefront
+    for (unsigned long long pm = __ballot(pending & lead); pm != 0ull; pm &= pm - 1ull) {  // (one search per env: its group's first lane)
         const int L = __builtin_ctzll(pm);
         const uint32_t ksL = (uint32_t)__builtin_amdgcn_readlane((int)ks[0], L);
         const int64_t eL = ((int64_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, L);
@@ -526,9 +541,9 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
         }
         RT cx, cy;
         candidate(ksL, eL, found, cx, cy);
-        if ((int)__lane_id() == L) { ox = cx; oy = cy; n_tried = found + 1; }
+        if (((int)__lane_id() >> gsh) == (L >> gsh)) { ox = cx; oy = cy; n_tried = found + 1; }  // the env's whole group takes the result
     }
-    if ((X.cand != nullptr) & (X.cand_used != nullptr) & need) X.cand_used[e] = n_tried;
+    if ((X.cand != nullptr) & (X.cand_used != nullptr) & need & lead) X.cand_used[e] = n_tried;
     if (X.opt_goal != nullptr) {
         g = load2<ST, RT>(X.opt_goal, 2 * e);  // PU:412-414
     } else {
@@ -570,8 +585,10 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = t < P.E;
-    const int64_t e = live ? t : P.E - 1;
+    const int lsh = X.lane_shift;                                   // 2^lsh lanes per env: the group runs the env redundantly
+    const bool lead = (t & ((1ll << lsh) - 1ll)) == 0;              // ... and its first lane stores
+    const bool live = lead & ((t >> lsh) < P.E);
+    const int64_t e = (t >> lsh) < P.E ? (t >> lsh) : P.E - 1;      // (groups past the last env shadow it; never stored)
     const int64_t env_global = P.env_id_offset + e;
     if constexpr (!FULL) stage_tables(lds, P.tables, P.table_bytes);
     const Tables<RT> T = make_tables<RT>(lds, P);
@@ -709,7 +726,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
         for (int i = 0; i < NM; ++i) rp[i] = p[i];
         RT rox = o.x, roy = o.y;
         bool rwc, rmc;
-        const PushObs<RT, NM> ro = push_reset_one<ST, RT, NM, NOISE, FULL>(P, Q, X, T, e, env_global, c, need, rp, rg, rox, roy, rwc, rmc);
+        const PushObs<RT, NM> ro = push_reset_one<ST, RT, NM, NOISE, FULL>(P, Q, X, T, e, env_global, c, need, lead, rp, rg, rox, roy, rwc, rmc);
         if (need) {
             g = rg;
 #pragma unroll
@@ -741,9 +758,31 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
     }
 }
 
+// log2 of the lanes every env gets: the most (up to 64) that keep the grid within one wavefront per SIMD (see the top of this file)
+static int push_lane_shift(int64_t E) {
+    static int simds = 0;  // (the devices of a node are alike)
+    if (simds == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        simds = 1024;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+    }
+    if (const char *f = std::getenv("GPR_PUSH_LANES")) {  // experiment knob: lanes per env (a power of two up to 64)
+        int sh = 0;
+        while ((2 << sh) <= std::atoi(f) && sh < 6) ++sh;
+        return sh;
+    }
+    int sh = 0;
+    while (sh < 6 && ((E << (sh + 1)) + 63) / 64 <= simds) ++sh;
+    return sh;
+}
 template <typename ST, typename RT, int NM, bool JERK, bool NOISE, bool FULL>
-static hipError_t launch_push3(bool is_reset, const KParams &P, const PushCst<RT> &Q, const PushPtrs &X, hipStream_t s) {
-    const unsigned grid = (unsigned)((P.E + BLOCK - 1) / BLOCK), lds = FULL ? 0u : P.table_bytes;
+static hipError_t launch_push3(bool is_reset, const KParams &P, const PushCst<RT> &Q, const PushPtrs &X0, hipStream_t s) {
+    const unsigned lds = FULL ? 0u : P.table_bytes;
+    PushPtrs X = X0;
+    // (a reset is short: one lane per env)
+    X.lane_shift = is_reset ? 0 : push_lane_shift(P.E);
+    const unsigned grid = (unsigned)(((P.E << X.lane_shift) + BLOCK - 1) / BLOCK);
     if (is_reset) hipLaunchKernelGGL((k_push<ST, RT, NM, JERK, NOISE, FULL, true>), dim3(grid), dim3(BLOCK), lds, s, P, Q, X);
     else hipLaunchKernelGGL((k_push<ST, RT, NM, JERK, NOISE, FULL, false>), dim3(grid), dim3(BLOCK), lds, s, P, Q, X);
     return hipGetLastError();
