@@ -46,7 +46,8 @@ class GprStepOut(C.Structure):
     _fields_ = [('observation_dev', C.c_void_p), ('achieved_goal_dev', C.c_void_p), ('desired_goal_dev', C.c_void_p),
                 ('reward_dev', C.c_void_p), ('terminated_dev', C.c_void_p), ('truncated_dev', C.c_void_p), ('is_success_dev', C.c_void_p),
                 ('mover_collision_dev', C.c_void_p), ('wall_collision_dev', C.c_void_p), ('final_observation_dev', C.c_void_p),
-                ('final_achieved_goal_dev', C.c_void_p), ('final_desired_goal_dev', C.c_void_p)]
+                ('final_achieved_goal_dev', C.c_void_p), ('final_desired_goal_dev', C.c_void_p), ('agent_observation_dev', C.c_void_p),
+                ('agent_reward_dev', C.c_void_p)]
 
 
 class GprPushParams(C.Structure):

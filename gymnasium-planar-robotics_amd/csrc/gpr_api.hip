@@ -253,6 +253,7 @@ KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
         P.terminated = out->terminated_dev; P.truncated = out->truncated_dev; P.is_success = out->is_success_dev;
         P.mover_collision = out->mover_collision_dev; P.wall_collision = out->wall_collision_dev;
         P.final_obs = out->final_observation_dev; P.final_ag = out->final_achieved_goal_dev; P.final_dg = out->final_desired_goal_dev;
+        P.agent_obs = out->agent_observation_dev; P.agent_reward = out->agent_reward_dev;
     }
     return P;
 }
@@ -265,6 +266,8 @@ int check_out(gpr_env *e, const gpr_step_out *o) {
     const bool any_final = o->final_observation_dev || o->final_achieved_goal_dev || o->final_desired_goal_dev;
     const bool all_final = o->final_observation_dev && o->final_achieved_goal_dev && o->final_desired_goal_dev;
     if (any_final && !all_final) return fail(e, GPR_E_INVALID, "gpr_step_out: set all three final_* pointers or none");
+    if ((o->agent_observation_dev != nullptr) != (o->agent_reward_dev != nullptr))
+        return fail(e, GPR_E_INVALID, "gpr_step_out: set both agent_observation_dev and agent_reward_dev or neither");
     return GPR_OK;
 }
 
@@ -308,6 +311,7 @@ template <typename RT> void fill_push(const gpr_env &e, const gpr_push_params &p
 int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, const void *opt_start = nullptr, const void *opt_goal = nullptr,
                 int32_t n_cand = 0, const void *cand = nullptr, int32_t *cand_used = nullptr) {
     if (const int rc = check_device(env, is_reset ? "gpr_push_reset" : "gpr_push_step")) return rc;
+    if (P.agent_obs != nullptr) return fail(env, GPR_E_UNSUPPORTED, "the pushing env has no per-agent views (agent_observation_dev must be NULL)");
     hipError_t he;
     PushPtrs X = env->push_ptrs;
     X.opt_start = opt_start; X.opt_goal = opt_goal;
@@ -608,6 +612,7 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
         adv(Q.terminated, i * ss_flag); adv(Q.truncated, i * ss_flag); adv(Q.is_success, i * ss_flag);
         adv(Q.mover_collision, i * ss_flag); adv(Q.wall_collision, i * ss_flag);
         if (Q.final_obs) { adv(Q.final_obs, i * ss_obs); adv(Q.final_ag, i * ss_goal); adv(Q.final_dg, i * ss_goal); }
+        if (Q.agent_obs) { adv(Q.agent_obs, i * E * M * (4 * M + 2) * sz); adv(Q.agent_reward, i * E * M * sz); }
         const uint64_t tick = env->tick + (uint64_t)i;
         Q.tick_lo = (uint32_t)tick; Q.tick_hi = (uint32_t)(tick >> 32);
     }

@@ -62,6 +62,8 @@ struct KParams {
     void *obs, *ag, *dg, *reward;
     uint8_t *terminated, *truncated, *is_success, *mover_collision, *wall_collision;
     void *final_obs, *final_ag, *final_dg;
+    // per-agent views written by the step kernel itself (gpr_step_out.agent_observation_dev / agent_reward_dev), nullable
+    void *agent_obs, *agent_reward;
     int32_t n_steps;            // gpr_step_n: env-steps per launch (1: gpr_step) ...
     const struct KParams *step_params;  // ... and (host side only) the device array of the n per-step parameter blocks
     uint32_t *counters;         // [wavefronts][6] episode counters (include/gpr.h: GPR_CNT_*), NULL = not counting

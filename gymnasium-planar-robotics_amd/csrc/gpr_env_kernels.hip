@@ -242,6 +242,35 @@ __device__ __forceinline__ void store_obs(const KParams &P, void *obs, void *ag,
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// per-agent views in the step kernel's epilogue (gpr_step_out.agent_observation_dev; layout: include/gpr.h, gpr_agent_views)
+// -----------------------------------------------------------------------------------------------------------------
+// The lanes of an env group hold every mover's observed velocity and position: agent i's row is its own six values plus, for every
+// other mover j in ascending order, (p_j - p_i, v_j - v_i) -- lane rotations inside the group. Differences are taken in the STORAGE
+// type on the values as stored, exactly as the stand-alone k_agent_views (gpr_ops_kernels.hip) forms them from memory.
+template <typename ST, int LPE, int D> struct ViewGather {
+    static __device__ __forceinline__ void run(ST px, ST py, ST vx, ST vy, int mv, int M, ST *row) {
+        if constexpr (D < LPE) {
+            const ST ox = rot<LPE, D>(px), oy = rot<LPE, D>(py), ovx = rot<LPE, D>(vx), ovy = rot<LPE, D>(vy);
+            const int j = (mv + D) & (LPE - 1);
+            if (j < M && mv < M) {  // (a lane that writes nothing is called with mv = LPE)
+                ST *dst = row + 6 + 4 * (j < mv ? j : j - 1);
+                dst[0] = ox - px; dst[1] = oy - py; dst[2] = ovx - vx; dst[3] = ovy - vy;
+            }
+            ViewGather<ST, LPE, D + 1>::run(px, py, vx, vy, mv, M, row);
+        }
+    }
+};
+// the env reward (PL:519-531) split per agent from the achieved / desired goal the reward was computed from, as stored
+template <typename ST> __device__ __forceinline__ ST agent_reward_of(const KParams &P, ST reward, ST ax, ST ay, ST gx, ST gy) {
+    const double r = (double)reward, rs = P.cd.reward_success, dx = (double)ax - (double)gx, dy = (double)ay - (double)gy;
+    const bool shared = (r == rs) | (r == -rs);
+    return shared ? (ST)r : (ST)(sqrt(dx * dx + dy * dy) <= P.cd.thr ? 0.0 : -1.0);
+}
+// bytes of LDS every wavefront of a step kernel owns: the velocity-reading rows of the cycle loop (12 rows + the zero row of 64
+// float2, or 6 + 1 rows of double2 in the parity loop) and, once the loop is through, the staging area of its agents' view rows
+constexpr int WAVE_SCRATCH_BYTES = 7 * 64 * 16;  // 7 168 >= 13 * 64 * 8
+
+// -----------------------------------------------------------------------------------------------------------------
 // step
 // -----------------------------------------------------------------------------------------------------------------
 // One env-step of every env of the block. MULTI (gpr_step_n): the block calls it once per step with that step's parameter block
@@ -285,6 +314,9 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
 #else
 #define GPR_WT(x)
 #endif
+    // one raw slice of LDS per wavefront: the velocity-reading rows of the cycle loops, then the staging area of the agent views
+    __shared__ __align__(16) unsigned char wave_scratch[BLOCK / 64][WAVE_SCRATCH_BYTES];
+    unsigned char *const my_scratch = wave_scratch[threadIdx.x >> 6];
     const int64_t env_block_base = (int64_t)blockIdx.x * (BLOCK / LPE);
     // RESET QUEUE of the block. A reset is a pure function of (seed, tick, env id): it does not need the env's final state, only
     // the knowledge THAT the env ends in this call -- and that is known early: a TimeLimit truncation (and a next-step-mode
@@ -304,7 +336,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         queued = true;
         if constexpr (MULTI) return;
         const int slot = atomicAdd(&reset_count, 1);
-        __hip_atomic_store(&reset_list[slot], (int)(envc - env_block_base) * 2 + (int)reset_only, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&reset_list[slot], (int)(threadIdx.x / LPE) * 2 + (int)reset_only, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (only live lanes queue)
     };
 
     // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
@@ -483,10 +515,10 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     int next_c = 0;  // wave-uniform: the first cycle at which the speed clamp has to be looked at again
     // velocity-reading rows of this wavefront's needy lanes (see the clamp path); row 0 is all zeros
     constexpr int VN_ROWS = 12;
-    __shared__ float2 vn_tab[BLOCK / 64][VN_ROWS + 1][64];
-    const int vn_wave = (int)(threadIdx.x >> 6);
-    vn_tab[vn_wave][0][__lane_id()] = make_float2(0.f, 0.f);
-    const float2 *vn_ptr = &vn_tab[vn_wave][0][0];  // per lane: my row (row 0 until the lane needs readings)
+    static_assert((VN_ROWS + 1) * 64 * sizeof(float2) <= WAVE_SCRATCH_BYTES, "reading rows exceed the wavefront's LDS slice");
+    float2 *const vn_tab = reinterpret_cast<float2 *>(my_scratch);  // [VN_ROWS + 1][64]
+    vn_tab[__lane_id()] = make_float2(0.f, 0.f);
+    const float2 *vn_ptr = vn_tab;  // per lane: my row (row 0 until the lane needs readings)
     int vn_rows = 0;                                 // wave-uniform: rows in use
     bool vn_on = !every;                  // false: every lane draws per cycle (eager mode, > VN_ROWS needy lanes, > 64 cycles)
     unsigned long long vn_uncovered = ~0ull;  // lanes that may NOT simply read their row: no row of their own yet (or !vn_on: all)
@@ -521,8 +553,8 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
             const R2<RT> n = rng_normal_pair<RT>(kL, S * (uint32_t)__lane_id());
             ++vn_rows;
             GPR_WT(++wt_rows;)
-            vn_tab[vn_wave][vn_rows][__lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
-            if ((int)__lane_id() == L) vn_ptr = &vn_tab[vn_wave][vn_rows][0];
+            vn_tab[vn_rows * 64 + __lane_id()] = make_float2(C.sig_v * n.x, C.sig_v * n.y);
+            if ((int)__lane_id() == L) vn_ptr = vn_tab + vn_rows * 64;
             vn_uncovered &= ~(1ull << L);
         }
         return true;
@@ -806,10 +838,10 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // velocity-reading rows (parity-mode loop), see the clamp path of the throughput loop; row 0 is all zeros
     constexpr int VG_ROWS = 6;
     typedef typename V2<RT>::type VgVec;
-    __shared__ VgVec vg_tab[(Math<RT>::literal && NOISE) ? BLOCK / 64 : 1][(Math<RT>::literal && NOISE) ? VG_ROWS + 1 : 1][(Math<RT>::literal && NOISE) ? 64 : 1];
-    const int vg_wave = (Math<RT>::literal && NOISE) ? (int)(threadIdx.x >> 6) : 0;
-    if constexpr (Math<RT>::literal && NOISE) { VgVec z; z.x = (RT)0; z.y = (RT)0; vg_tab[vg_wave][0][__lane_id()] = z; }
-    const VgVec *vg_ptr = &vg_tab[vg_wave][0][0];
+    static_assert((VG_ROWS + 1) * 64 * sizeof(VgVec) <= WAVE_SCRATCH_BYTES, "reading rows exceed the wavefront's LDS slice");
+    VgVec *const vg_tab = reinterpret_cast<VgVec *>(my_scratch);  // [VG_ROWS + 1][64]
+    if constexpr (Math<RT>::literal && NOISE) { VgVec z; z.x = (RT)0; z.y = (RT)0; vg_tab[__lane_id()] = z; }
+    const VgVec *vg_ptr = vg_tab;
     int vg_rows = 0;
     bool vg_on = true;
     unsigned long long vg_uncovered = ~0ull;
@@ -842,8 +874,8 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                                 ++vg_rows;
                                 GPR_WT(++wt_rows;)
                                 VgVec w; w.x = C.sig_v * n.x; w.y = C.sig_v * n.y;
-                                vg_tab[vg_wave][vg_rows][__lane_id()] = w;
-                                if ((int)__lane_id() == L) vg_ptr = &vg_tab[vg_wave][vg_rows][0];
+                                vg_tab[vg_rows * 64 + __lane_id()] = w;
+                                if ((int)__lane_id() == L) vg_ptr = vg_tab + vg_rows * 64;
                                 vg_uncovered &= ~(1ull << L);
                             }
                         }
@@ -1080,6 +1112,22 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     }
     GPR_WT(wt_loop1 = __builtin_amdgcn_s_memtime();)
     }
+    // EPILOGUE. Everything below addresses memory through indices that are derived AGAIN here from the thread index (made opaque to the
+    // optimiser): the 64-bit element indices of the prologue's loads would otherwise stay in vector registers across the cycle loops --
+    // the registers the loops were budgeted to the last one for (4 wavefronts per SIMD), i.e. spills to scratch memory, whose mere
+    // presence costs a launch ~2 us (measured: 17.1 -> 19.0 us per step when the view rows below first pushed seven of them out).
+    unsigned tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    {
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + tid_e;
+    const int mv = (int)(tid_e & (LPE - 1));
+    const int64_t env = t / LPE;
+    const bool live_env = env < P.E;
+    const bool live = live_env & (mv < M);
+    const int64_t envc = live_env ? env : P.E - 1;
+    const int mvc = mv < M ? mv : M - 1;
+    const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
+    const int64_t cnt_row = t >> 6;
     wc_m = group_or<LPE>(wc_m);
     mc_m = group_or<LPE>(mc_m);
     const bool wc_step = lane_of(wc_m), mc_step = lane_of(mc_m);
@@ -1127,6 +1175,52 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         if (need & (mv == 0) & !queued) enqueue(reset_first);  // (a success, or a collision found by the generic loop)
     }
 
+    // PER-AGENT VIEWS (gpr_step_out.agent_observation_dev), same launch: the rows of this wavefront's agents ((env, mover) in lane order)
+    // are consecutive in agent_obs, 4M + 2 values each (264 B with 16 movers). Written by their own lanes they would be 64 scattered
+    // pieces per store instruction; so the wavefront assembles them in its LDS slice (the reading rows are dead by now) -- as many
+    // whole envs per pass as fit -- and streams every env's M rows out as one span. An env that is reset in this call gets its rows
+    // from whoever serves its reset (serve() below): its span is skipped here. The per-agent reward always comes from the state the
+    // env reward was computed from, i.e. from here.
+    if (P.agent_obs != nullptr) {  // (wave-uniform)
+        const int W = 4 * M + 2;
+        ST *const aobs = static_cast<ST *>(P.agent_obs);
+        const ST vx = (ST)o.vel.x, vy = (ST)o.vel.y, px = (ST)o.ag.x, py = (ST)o.ag.y, gx = (ST)g.x, gy = (ST)g.y;
+        if (live & !reset_first) static_cast<ST *>(P.agent_reward)[envc * M + mv] = agent_reward_of<ST>(P, (ST)o.reward, px, py, gx, gy);
+        const int lane = (int)__lane_id(), ei = lane / LPE;
+        const int64_t env_w0 = (t - lane) / LPE;  // first env of this wavefront
+        int64_t n_env64 = P.E - env_w0;
+        const int n_env = (int)(n_env64 < 0 ? 0 : (n_env64 > 64 / LPE ? 64 / LPE : n_env64));
+        const unsigned long long need_m = __ballot(need);
+        const int env_bytes = M * W * (int)sizeof(ST);
+        int epp = WAVE_SCRATCH_BYTES / env_bytes;  // whole envs per pass
+        epp = epp > 64 / LPE ? 64 / LPE : epp;
+        if (epp >= 1) {
+            ST *const slice = reinterpret_cast<ST *>(my_scratch);
+            for (int e0 = 0; e0 < n_env; e0 += epp) {
+                const bool mine = live & (ei >= e0) & (ei < e0 + epp);
+                ST *row = slice + ((mine ? ei - e0 : 0) * M + mvc) * W;
+                if (mine) { row[0] = vx; row[1] = vy; row[2] = px; row[3] = py; row[4] = gx; row[5] = gy; }
+                ViewGather<ST, LPE, 1>::run(px, py, vx, vy, mine ? mv : LPE, M, row);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wavefront's LDS writes have landed
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int n8 = env_bytes / 8;  // (M W is even: an env's rows are a whole number of 8-byte pieces, 8-byte aligned)
+                for (int k = 0; k < epp && e0 + k < n_env; ++k) {
+                    if ((need_m >> ((e0 + k) * LPE)) & 1ull) continue;  // (wave-uniform) reset in this call: rows come from the reset
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(slice + k * M * W);
+                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(aobs + (env_w0 + e0 + k) * (int64_t)M * W);
+                    for (int i = lane; i < n8; i += 64) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next pass overwrites the slice: LDS operations of a wavefront stay in order)
+            }
+        } else {  // (an env's rows do not fit the slice: f64 storage with 15 or 16 movers) every lane stores its own row
+            const bool wr = live & !need;
+            ST *row = aobs + (envc * M + mvc) * (int64_t)W;
+            if (wr) { row[0] = vx; row[1] = vy; row[2] = px; row[3] = py; row[4] = gx; row[5] = gy; }
+            ViewGather<ST, LPE, 1>::run(px, py, vx, vy, wr ? mv : LPE, M, row);
+        }
+    }
+
     // SERVING THE QUEUE: claim up to 64 / LPE queued envs at a time until nothing unclaimed is left; the lane groups a claim
     // leaves idle join the others as parallel trial slots (group_reset: S groups per env). Whatever is queued later is served
     // by a wavefront that finishes later -- at the latest by the one that queued it.
@@ -1156,6 +1250,15 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
             store_obs<ST, RT, JERK>(P, P.obs, P.ag, P.dg, renv, mv, ridx, ro.vel, zero, ro.ag, rg, P.dg != P.goal);
             // an env that only resets in this call: the reset IS the call's result (BE:1797-1831)
             if ((mv == 0) & rfirst) store_env_scalars<ST, RT>(P, renv, 0, (RT)0, false, false, ro.is_success, rmc, rwc);
+        }
+        if (P.agent_obs != nullptr) {  // (wave-uniform) the reset env's view rows: first observation of the new episode
+            const bool wr = rlive & ((gi & (S - 1)) == 0);
+            const int W = 4 * M + 2;
+            const ST vx = (ST)ro.vel.x, vy = (ST)ro.vel.y, px = (ST)ro.ag.x, py = (ST)ro.ag.y, gx = (ST)rg.x, gy = (ST)rg.y;
+            ST *row = static_cast<ST *>(P.agent_obs) + ((have ? renv : 0) * M + mvc) * (int64_t)W;
+            if (wr) { row[0] = vx; row[1] = vy; row[2] = px; row[3] = py; row[4] = gx; row[5] = gy; }
+            ViewGather<ST, LPE, 1>::run(px, py, vx, vy, wr ? mv : LPE, M, row);
+            if (wr & rfirst) static_cast<ST *>(P.agent_reward)[renv * M + mv] = (ST)0;  // (a call that only resets carries reward 0, for every agent too)
         }
         (void)n;
     };
@@ -1241,6 +1344,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         d[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_ID, XCC_ID
     }
 #endif
+    }  // (epilogue)
 #undef GPR_WT
 }
 

@@ -194,7 +194,9 @@ __global__ void __launch_bounds__(AV_BLOCK) k_agent_views(const KParams P, int o
         }
         const double r = (double)reward[envc], rs = P.cd.reward_success, dx = (double)rpx - (double)rgx, dy = (double)rpy - (double)rgy;
         const bool shared = (r == rs) | (r == -rs);  // PL:529-531
-        agent_reward[envc * M + mvc] = shared ? (ST)r : (ST)(sqrt(dx * dx + dy * dy) <= P.cd.thr ? 0.0 : -1.0);
+        // next-step autoreset: a call that only reset the env (its step count is 0 afterwards) carries reward 0, for every agent too
+        const bool reset_only = (P.autoreset == 2) & (P.elapsed[envc] == 0);
+        agent_reward[envc * M + mvc] = reset_only ? (ST)0 : shared ? (ST)r : (ST)(sqrt(dx * dx + dy * dy) <= P.cd.thr ? 0.0 : -1.0);
     }
 }
 template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, void *agent_obs, void *agent_reward, hipStream_t s) {

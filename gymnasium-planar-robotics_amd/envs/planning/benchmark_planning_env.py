@@ -251,9 +251,10 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
     # ------------------------------------------------------------------------------------------------------------
     # open-loop rollouts: n env-steps per kernel launch (gpr_step_n)
     # ------------------------------------------------------------------------------------------------------------
-    def alloc_rollout(self, n_steps: int) -> dict[str, torch.Tensor]:
+    def alloc_rollout(self, n_steps: int, agent_views: bool = False) -> dict[str, torch.Tensor]:
         """[n_steps, num_envs, ...] tensors for everything ``step()`` returns (observation dict, reward, terminated, truncated, the
-        three info flags and, with same-step autoreset, the terminal observations), to be filled by ``step_n``."""
+        three info flags and, with same-step autoreset, the terminal observations), to be filled by ``step_n``. ``agent_views``: also
+        the per-agent views of the PettingZoo-parallel layer ([n_steps, num_envs, M, 4M+2] / [n_steps, num_envs, M], include/gpr.h)."""
         E, M, dev, dt, T = self.num_envs, self.num_movers, self.device, self.dtype, int(n_steps)
         z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         r = dict(observation=z(T, E, self.obs_dim), achieved_goal=z(T, E, 2 * M), desired_goal=z(T, E, 2 * M), reward=z(T, E))
@@ -266,6 +267,9 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
                                        r['terminated'].data_ptr(), r['truncated'].data_ptr(), r['is_success'].data_ptr(),
                                        r['mover_collision'].data_ptr(), r['wall_collision'].data_ptr(), fin('final_observation'),
                                        fin('final_achieved_goal'), fin('final_desired_goal'))
+        if agent_views:
+            r.update(agent_observation=z(T, E, M, 4 * M + 2), agent_reward=z(T, E, M))
+            r['_out'].agent_observation_dev, r['_out'].agent_reward_dev = r['agent_observation'].data_ptr(), r['agent_reward'].data_ptr()
         return r
 
     def step_n(self, actions: torch.Tensor, rollout: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:

@@ -8,7 +8,9 @@ truncation are exactly those of the single-agent env (one fused kernel launch), 
 this engine's own definition (include/gpr.h, ``gpr_agent_views``):
 
 * ``observations[agent]`` ``[E, 4M+2]``: own velocity, own position, own goal, then for every other mover in ascending index its
-  position and velocity relative to the agent (a lane-permute gather inside the env's wavefront group, no extra memory pass);
+  position and velocity relative to the agent -- a lane-permute gather inside the env's wavefront group in the step kernel's own
+  epilogue (``gpr_step_out.agent_observation_dev``): ``step()`` is ONE kernel launch, nothing is re-read; only ``reset()`` runs the
+  stand-alone gather ``gpr_agent_views``;
 * ``rewards[agent]`` ``[E]``: the env reward of PL:519-531 split per agent: -50 / +50 for every agent on collision / joint
   success, otherwise -1 while the agent's own goal is not reached, 0 once it is (summing to the single-agent reward). With
   same-step autoreset the reward of an env that ended in this call (also by TimeLimit) is computed from its TERMINAL
@@ -47,6 +49,10 @@ class VecBenchmarkPlanningParallelEnv(spaces.ParallelEnvBase):
             # the per-agent dict entries are fixed views of the gather kernel's two output tensors: built once
             self._obs_views = {a: self._agent_obs[:, i, :] for i, a in enumerate(self.agents)}
             self._rew_views = {a: self._agent_reward[:, i] for i, a in enumerate(self.agents)}
+            # step(): the step kernel writes the views itself; reset(): the stand-alone gather over the stored outputs
+            self._out_reset = _native.GprStepOut()
+            C.memmove(C.byref(self._out_reset), C.byref(e._out), C.sizeof(self._out_reset))
+            e._out.agent_observation_dev, e._out.agent_reward_dev = self._agent_obs.data_ptr(), self._agent_reward.data_ptr()
 
     def observation_space(self, agent: str) -> spaces.Box:
         return self._obs_space
@@ -55,9 +61,10 @@ class VecBenchmarkPlanningParallelEnv(spaces.ParallelEnvBase):
         return self._act_space
 
     def _views(self):
+        """the stand-alone gather (one more launch) over the outputs of the last reset() / step()"""
         e = self.env
         with torch.cuda.device(e.device):
-            _native.check(e._lib.gpr_agent_views(e._handle, C.byref(e._out), self._agent_obs.data_ptr(), self._agent_reward.data_ptr(),
+            _native.check(e._lib.gpr_agent_views(e._handle, C.byref(self._out_reset), self._agent_obs.data_ptr(), self._agent_reward.data_ptr(),
                                                  e._stream()), e._handle)
         return dict(self._obs_views), dict(self._rew_views)
 
@@ -81,8 +88,8 @@ class VecBenchmarkPlanningParallelEnv(spaces.ParallelEnvBase):
             action = self._action
         else:
             action = torch.as_tensor(actions, device=e.device).to(e.dtype).reshape(e.num_envs, 2 * self.num_movers)
-        _, _, terminated, truncated, info = e.step(action)
-        obs, rew = self._views()
+        _, _, terminated, truncated, info = e.step(action)  # (one launch: the views are written by the step kernel)
+        obs, rew = dict(self._obs_views), dict(self._rew_views)
         return obs, rew, {a: terminated for a in self.agents}, {a: truncated for a in self.agents}, {a: info for a in self.agents}
 
     def state(self) -> torch.Tensor:

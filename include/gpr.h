@@ -94,6 +94,11 @@ typedef struct {
     uint8_t *terminated_dev, *truncated_dev;                        /* [E], PL:459-479 / TimeLimit */
     uint8_t *is_success_dev, *mover_collision_dev, *wall_collision_dev; /* [E] info dict, PL:596-601 */
     void *final_observation_dev, *final_achieved_goal_dev, *final_desired_goal_dev; /* nullable; same-step autoreset only */
+    /* nullable (both or none): per-agent views of a PettingZoo-parallel layer, written by gpr_step / gpr_step_n IN THE SAME LAUNCH
+     * (the step kernel holds every mover's observation in the lanes of its env group): agent_observation_dev [E][M][4M+2] real,
+     * agent_reward_dev [E][M] real -- layout and semantics as documented at gpr_agent_views below, which produces the same bytes from
+     * the stored outputs in a launch of its own (used after gpr_reset, whose kernel does not write views). */
+    void *agent_observation_dev, *agent_reward_dev;
 } gpr_step_out;
 
 typedef struct gpr_env gpr_env;

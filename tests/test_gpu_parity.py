@@ -10,6 +10,8 @@ Tolerances
                         wherever the oracle's smallest decision margin exceeds 1e-5; the fraction of envs below that margin
                         is bounded
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -235,7 +237,7 @@ def _make_pair(gpr, oracle, layout, M, E, precision, kw, env_id_offset=0):
     okw = dict(kw)
     okw.setdefault('std_noise', 1e-5)
     oenv = oracle.OraclePlanningEnv(layout, M, E, autoreset=autoreset, max_episode_steps=mes, storage_f32=(precision != 'f64'),
-                                    env_id_offset=env_id_offset, **okw)
+                                    env_id_offset=env_id_offset, num_threads=min(16, os.cpu_count() or 1) if E >= 1024 else 1, **okw)
     return genv, oenv
 
 
@@ -328,6 +330,8 @@ FREE_RUNNING_F64 = [
     (np.ones((5, 5)), 3, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.002}}),  # rectangle tests
     (np.ones((6, 6)), 4, {'learn_jerk': True}),                                                         # two literal clamps per cycle
     (np.ones((8, 8)), 8, {'std_noise': np.array([1e-4, 2e-4, 0.0])}),                                    # wide noise bands, 8 lanes per env
+    (np.ones((10, 10)), 16, {'E': 2048, 'steps': 60}),   # BASELINE config 5's shape: parallel reset trials (~45 rejections per reset), 16 lanes per env
+    (np.ones((8, 8)), 8, {'E': 4096, 'steps': 60}),      # BASELINE config 4's shape
 ]
 
 
@@ -335,12 +339,14 @@ FREE_RUNNING_F64 = [
 def test_free_running_f64_matches_oracle_exactly(gpr, oracle, cfg_i):
     """no teacher forcing: 120 steps, every episode boundary, every auto-reset sample must agree with the oracle"""
     layout, M, kw = FREE_RUNNING_F64[cfg_i]
-    E = 256
+    kw = dict(kw)
+    E, n_steps = kw.pop('E', 256), kw.pop('steps', 120)
     genv, oenv = _make_pair(gpr, oracle, layout, M, E, 'f64', kw)
     genv.reset(seed=7); oenv.reset(seed=7)
     rng = np.random.default_rng(3)
     lim = genv.j_max if genv.learn_jerk else genv.a_max
-    for step in range(120):
+    n_done = 0
+    for step in range(n_steps):
         a = rng.uniform(-lim, lim, size=(E, 2 * M))
         obs, rew, term, trunc, info = genv.step(torch.as_tensor(a, device=genv.device))
         o = oenv.step(a)
@@ -352,10 +358,13 @@ def test_free_running_f64_matches_oracle_exactly(gpr, oracle, cfg_i):
         fo = info['final_obs']
         assert np.abs(_g(fo['achieved_goal'])[done] - o['final_achieved_goal'][done]).max(initial=0) < 1e-9
         assert np.abs(_g(fo['observation'])[done] - o['final_observation'][done]).max(initial=0) < 1e-9
+        n_done += int(done.sum())
+    record_metric(f'free_running_f64[{cfg_i}: {M} movers x {E} envs]', env_steps=E * n_steps, auto_resets_compared=n_done, mismatches=0)
+    assert n_done > E // 2
     genv.close()
 
 
-@pytest.mark.parametrize('M,n,E', [(4, 6, 4096), (8, 8, 512), (16, 10, 128), (4, 'box', 1024), (3, 'holes', 1024)])
+@pytest.mark.parametrize('M,n,E', [(4, 6, 4096), (8, 8, 4096), (16, 10, 2048), (4, 'box', 1024), (3, 'holes', 1024)])
 def test_free_running_f32_follows_the_oracle_within_1e_4(gpr, oracle, M, n, E):
     """The north-star statement, in the benchmark's precision and without teacher forcing: same seed, same actions, 100 steps
     (two full episodes, every auto-reset in between); every env is followed until the first env-step in which the float engine
@@ -481,13 +490,18 @@ def test_lazy_noise_is_exact(gpr, monkeypatch):
         lazy.close(); eager.close()
 
 
-@pytest.mark.parametrize('M,precision', [(1, 'f32'), (3, 'f64'), (4, 'f32'), (8, 'f32'), (16, 'f32')])
-def test_parallel_env_agent_views(gpr, M, precision):
-    """PettingZoo-parallel layer: the per-agent gather kernel against a plain NumPy statement of its documented layout
-    (engine-defined, the reference has no multi-agent semantics), and consistency with the single-agent outputs."""
+@pytest.mark.parametrize('M,precision,kw', [(1, 'f32', {}), (3, 'f64', {}), (4, 'f32', {}), (8, 'f32', {}), (16, 'f32', {}), (7, 'f64', {}), (15, 'f64', {}),
+                                            (16, 'f64', {}), (4, 'f32', {'autoreset_mode': 'next_step'}), (5, 'f32_f64acc', {'autoreset_mode': 'disabled'}),
+                                            (4, 'f32', {'learn_jerk': True})])
+def test_parallel_env_agent_views(gpr, M, precision, kw):
+    """PettingZoo-parallel layer: the per-agent views -- written by the step kernel's own epilogue (one launch per step()) -- against a
+    plain NumPy statement of their documented layout (engine-defined, the reference has no multi-agent semantics), against the
+    stand-alone gather kernel over the stored outputs (bit for bit), and consistency with the single-agent outputs."""
     E = 200
     n = max(6, int(np.ceil(np.sqrt(M))) * 3)
-    penv = gpr.VecBenchmarkPlanningParallelEnv(np.ones((n, n)), M, num_envs=E, precision=precision)
+    penv = gpr.VecBenchmarkPlanningParallelEnv(np.ones((n, n)), M, num_envs=E, precision=precision, **kw)
+    same_step = kw.get('autoreset_mode', 'same_step') == 'same_step'
+    lim = penv.env.j_max if penv.env.learn_jerk else penv.env.a_max
     assert penv.agents == [f'mover_{i}' for i in range(M)] and penv.observation_space('mover_0').shape == (4 * M + 2,)
     obs, infos = penv.reset(seed=2)
     g = torch.Generator(device='cuda').manual_seed(0)
@@ -495,17 +509,25 @@ def test_parallel_env_agent_views(gpr, M, precision):
     for step in range(60):  # past the TimeLimit (50): truncated envs are auto-reset in the same call
         # (the first half of the envs never accelerates: those envs live to the TimeLimit)
         still = (torch.arange(E, device='cuda') < E // 2).unsqueeze(1)
-        act = {a: (torch.rand(E, 2, device='cuda', generator=g) * 20 - 10).masked_fill(still, 0.0) for a in penv.agents}
+        act = {a: ((torch.rand(E, 2, device='cuda', generator=g) * 2 - 1) * lim).masked_fill(still, 0.0) for a in penv.agents}
         obs, rew, term, trunc, infos = penv.step(act)
         e = penv.env
-        v = e._obs['observation'].double().cpu().numpy().reshape(E, M, 2); p = e._obs['achieved_goal'].double().cpu().numpy().reshape(E, M, 2)
+        if True:  # the stand-alone gather over the stored outputs writes the same bytes
+            fused_o, fused_r = penv._agent_obs.clone(), penv._agent_reward.clone()
+            penv._agent_obs.fill_(-7.0); penv._agent_reward.fill_(-7.0)
+            penv._views()
+            assert torch.equal(fused_o, penv._agent_obs) and torch.equal(fused_r, penv._agent_reward), step
+        v = e._obs['observation'].double().cpu().numpy().reshape(E, -1)[:, :2 * M].reshape(E, M, 2); p = e._obs['achieved_goal'].double().cpu().numpy().reshape(E, M, 2)
         gl = e._obs['desired_goal'].double().cpu().numpy().reshape(E, M, 2); r = e._reward.double().cpu().numpy()
         # the reward of an env that ended in this call belongs to its TERMINAL state (info['final_obs']), not to the first
         # observation of the new episode that same-step autoreset returns
-        done = (e._terminated | e._truncated).bool().cpu().numpy()
+        done = (e._terminated | e._truncated).bool().cpu().numpy() & same_step
         n_trunc += int(e._truncated.sum())
         fp = e._final['achieved_goal'].double().cpu().numpy().reshape(E, M, 2); fg = e._final['desired_goal'].double().cpu().numpy().reshape(E, M, 2)
         rp = np.where(done[:, None, None], fp, p); rg = np.where(done[:, None, None], fg, gl)
+        if not same_step and kw.get('autoreset_mode') == 'disabled' and step == 55:
+            penv.reset(seed=step)  # (nobody resets a finished env in this mode)
+            continue
         tot = np.zeros(E)
         for i, a in enumerate(penv.agents):
             exp = [v[:, i], p[:, i], gl[:, i]]
@@ -517,13 +539,30 @@ def test_parallel_env_agent_views(gpr, M, precision):
             assert np.abs(got - exp).max() < (1e-12 if precision == 'f64' else 1e-6), (step, a)
             shared = (r == 50) | (r == -50)
             own = np.where(np.linalg.norm(rp[:, i] - rg[:, i], axis=1) <= 0.1, 0.0, -1.0)
+            if kw.get('autoreset_mode') == 'next_step':  # a call that only reset the env (step count 0 afterwards): reward 0 for every agent
+                own = np.where(e.elapsed_steps.cpu().numpy() == 0, 0.0, own)
             assert np.array_equal(rew[a].double().cpu().numpy(), np.where(shared, r, own))
             tot += np.where(shared, 0.0, own)
             assert term[a] is term['mover_0'] and torch.equal(term[a], e._terminated.view(torch.bool))
         assert np.array_equal(tot[~shared], r[~shared])  # the per-agent rewards add up to the env reward (PL:530), truncated envs included
     assert n_trunc > 0
-    assert penv.state().shape == (E, 6 * M)
+    assert penv.state().shape[0] == E
     penv.close()
+
+
+def test_step_n_writes_agent_views_per_step(gpr):
+    """gpr_step_n with agent_observation_dev / agent_reward_dev bound: row i holds what the i-th step() + gather would have returned"""
+    E, M, T = 1500, 4, 55
+    lay = np.ones((6, 6))
+    a = gpr.VecBenchmarkPlanningParallelEnv(lay, M, num_envs=E); b = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E)
+    a.reset(seed=3); b.reset(seed=3)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    acts = torch.rand(T, E, 2 * M, device='cuda', generator=g) * 20 - 10
+    roll = b.step_n(acts, b.alloc_rollout(T, agent_views=True))
+    for t in range(T):
+        a.step(acts[t])
+        assert torch.equal(a._agent_obs, roll['agent_observation'][t]) and torch.equal(a._agent_reward, roll['agent_reward'][t]), t
+    a.close(); b.close()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
