@@ -10,12 +10,13 @@ straight into a [T = 50, E, .] rollout buffer. Inputs (a ring of pre-generated r
 region. Episode phases are desynchronised before the warm-up (elapsed-step counters drawn uniformly from [0, 50)), so that even a
 short timed window sees the steady-state TimeLimit rate instead of a burst every 50 steps.
 
-Sub-batches (--sub-batches S, default 2): the rank's 65 536 envs are stepped as S contiguous sub-batches, each with its own handle and
+Sub-batches (--sub-batches S, default 4): the rank's 65 536 envs are stepped as S contiguous sub-batches, each with its own handle and
 its own HIP stream, all S kernels launched by ONE C-ABI call per env-step (`gpr_step_many`). A step kernel lasts as long as its slowest
 wavefront while most SIMDs have run out of work; with S independent launches in flight the tail of one sub-batch overlaps with the
-bulk of another (measured, MI355X: S = 1 17.2 us per env-step of 65 536 envs, S = 2 13.7; more sub-batches need more than the 3.5 us of
-host time a launch costs and more hardware queues than the runtime's default four: S = 4 12.7 us with GPU_MAX_HW_QUEUES=8 in short bursts,
-host-bound in a sustained loop; a hipGraph of S kernel nodes costs 9.5 us per node to launch on ROCm 7.2 -- scratch/ubench/graphlaunch.hip).
+bulk of another (measured, MI355X, us per env-step of 65 536 envs: S = 1 17.7, S = 2 14.1, S = 4 13.2; S = 8 43 -- the runtime maps streams
+onto four hardware queues and two streams on one queue run strictly one after the other, which is also why the streams are probed for
+real overlap when the env is built, gpr_streams_overlap; launches 1..S-1 are issued by worker threads of the library, a launch costs the
+host 3.5 us; a hipGraph of S kernel nodes costs 9.5 us per node to launch on ROCm 7.2 -- scratch/ubench/graphlaunch.hip).
 Closed-loop legal (every sub-batch is its own observation -> policy -> action -> step loop on its own stream) and bit
 for bit the results of the single launch (random streams are keyed by global env id). `config.single_launch` is the S = 1 number.
 
@@ -174,7 +175,10 @@ class Pass:
         kw = dict(num_envs=envs, device=self.device, std_noise=std_noise, precision=precision, env_id_offset=rank * envs, collision_params=collision_params)
         if sub > 1:
             self.env = gpr.VecBenchmarkPlanningEnvSubBatched(np.ones((tiles, tiles)), self.M, num_sub_batches=sub, **kw)
+            self.S = sub = self.env.num_sub_batches  # (as many as there are streams that really overlap on this device)
             self.streams = self.env.streams
+            if sub == 1:
+                self.env, self.streams = self.env.subs[0], [torch.cuda.current_stream(self.device)]
         else:
             self.env = gpr.VecBenchmarkPlanningEnv(np.ones((tiles, tiles)), self.M, **kw)
             self.streams = [torch.cuda.current_stream(self.device)]
@@ -381,7 +385,7 @@ def main():
     ap.add_argument('--movers', type=int, default=4)
     ap.add_argument('--tiles', type=int, default=6)
     ap.add_argument('--precision', default='f32', choices=['f32', 'f32_f64acc', 'f64'])
-    ap.add_argument('--sub-batches', type=int, default=2, help='sub-batches (handles + HIP streams) the rank\'s envs are stepped as; 1 = one launch per step')
+    ap.add_argument('--sub-batches', type=int, default=4, help='sub-batches (handles + HIP streams) the rank\'s envs are stepped as; 1 = one launch per step')
     ap.add_argument('--min-seconds', type=float, default=0.1, help='minimum length of every timed region (blocks of --steps are repeated)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -2,6 +2,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -328,7 +333,107 @@ int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, co
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LAUNCH WORKERS (gpr_step_many). A kernel launch costs the host ~3.5 us (scratch/ubench/graphlaunch.hip: 3.46 us per launch issued from
+// one thread, 19.6 us for four on four streams in a sustained loop) -- as long as a 16 384-env sub-batch takes the GPU. Launches on
+// DIFFERENT streams from DIFFERENT host threads do run in parallel (4.3 us for the same four), so gpr_step_many hands launch i > 0 to
+// worker thread i and issues launch 0 itself. A worker spins on its mailbox while steps keep coming (a step is due every ~13 us) and
+// goes to sleep on a condition variable after ~200 us without work, so an idle process burns nothing. Workers are created on first
+// use, never destroyed (a process that is exiting must not join threads that may be inside the HIP runtime).
+// GPR_LAUNCH_THREADS=0 keeps every launch on the calling thread.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct LaunchJob {
+    gpr_env *env = nullptr;
+    const void *action = nullptr;
+    const gpr_step_out *out = nullptr;
+    void *stream = nullptr;
+    int rc = GPR_OK;
+};
+struct LaunchWorker {
+    std::atomic<int> state{0};  // 0 idle, 1 job posted, 2 job done
+    LaunchJob job;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<bool> asleep{false};
+    int device = -1;
+    void run() {
+        for (;;) {
+            int spins = 0;
+            while (state.load(std::memory_order_acquire) != 1) {
+                if (++spins < 20000) {  // ~200 us of polling
+                    __builtin_ia32_pause();
+                } else {
+                    std::unique_lock<std::mutex> lk(m);
+                    asleep.store(true, std::memory_order_release);
+                    cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1; });
+                    asleep.store(false, std::memory_order_release);
+                    spins = 0;
+                }
+            }
+            if (job.env->device != device) { device = job.env->device; (void)hipSetDevice(device); }  // (the current device is per thread)
+            job.rc = gpr_step(job.env, job.action, job.out, job.stream);
+            state.store(2, std::memory_order_release);
+        }
+    }
+    void post(const LaunchJob &j) {
+        job = j;
+        state.store(1, std::memory_order_release);
+        if (asleep.load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> lk(m);
+            cv.notify_one();
+        }
+    }
+    int wait() {
+        while (state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+        const int rc = job.rc;
+        state.store(0, std::memory_order_relaxed);
+        return rc;
+    }
+};
+constexpr int MAX_LAUNCH_WORKERS = 7;
+LaunchWorker *launch_worker(int i) {  // worker i, created on first use (called by one thread at a time per process: gpr_step_many's lock)
+    static LaunchWorker *pool[MAX_LAUNCH_WORKERS] = {};
+    if (!pool[i]) {
+        pool[i] = new LaunchWorker();
+        std::thread([w = pool[i]] { w->run(); }).detach();
+    }
+    return pool[i];
+}
+bool launch_threads_enabled() {
+    static const bool on = [] { const char *e = std::getenv("GPR_LAUNCH_THREADS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+}  // namespace
+
+// one wavefront that keeps a queue busy for `ticks` of the 100 MHz wall clock (gpr_streams_overlap)
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 extern "C" {
+
+int gpr_streams_overlap(void *stream_a, void *stream_b, int32_t *overlap_out) {
+    if (!overlap_out || stream_a == stream_b) return fail(nullptr, GPR_E_INVALID, "gpr_streams_overlap: two different streams and an output are needed");
+    hipStream_t a = as_stream(stream_a), b = as_stream(stream_b);
+    hipError_t he = hipStreamSynchronize(a);
+    if (he == hipSuccess) he = hipStreamSynchronize(b);
+    if (he != hipSuccess) return fail_hip(nullptr, he, "gpr_streams_overlap");
+    constexpr long long TICKS = 15000;  // 150 us per kernel: together 150 us on two hardware queues, 300 us on one
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {  // (the first launch on a fresh stream also creates its queue)
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, TICKS);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, TICKS);
+        he = hipStreamSynchronize(a);
+        if (he == hipSuccess) he = hipStreamSynchronize(b);
+        if (he != hipSuccess) return fail_hip(nullptr, he, "gpr_streams_overlap");
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    *overlap_out = best < 235.0 ? 1 : 0;
+    return GPR_OK;
+}
 
 const char *gpr_version(void) { return "gpr-hip 0.1 (gfx950; rng gpr-rng-v1; one lane per mover)"; }
 
@@ -558,11 +663,32 @@ int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_de
         const int rc = check_out(envs[i], outs[i]);
         if (rc != GPR_OK) return rc;
     }
+    if (n == 1 || !launch_threads_enabled()) {
+        for (int32_t i = 0; i < n; ++i) {
+            const int rc = gpr_step(envs[i], actions_dev[i], outs[i], hip_streams[i]);
+            if (rc != GPR_OK) return rc;
+        }
+        return GPR_OK;
+    }
+    // launches 1 .. n-1 go to the launch workers (see LaunchWorker), launch 0 is issued here; handles beyond the pool stay on this thread
+    static std::mutex pool_lock;  // (one gpr_step_many at a time per process uses the workers)
+    std::lock_guard<std::mutex> lk(pool_lock);
     for (int32_t i = 0; i < n; ++i) {
-        const int rc = gpr_step(envs[i], actions_dev[i], outs[i], hip_streams[i]);
+        const int rc = check_device(envs[i], "gpr_step_many");  // (the workers set their own current device: check the caller's here)
         if (rc != GPR_OK) return rc;
     }
-    return GPR_OK;
+    const int32_t n_workers = std::min<int32_t>(n - 1, MAX_LAUNCH_WORKERS);
+    for (int32_t w = 0; w < n_workers; ++w) launch_worker(w)->post(LaunchJob{envs[1 + w], actions_dev[1 + w], outs[1 + w], hip_streams[1 + w], GPR_OK});
+    int rc = gpr_step(envs[0], actions_dev[0], outs[0], hip_streams[0]);
+    for (int32_t i = 1 + n_workers; i < n; ++i) {
+        const int r = gpr_step(envs[i], actions_dev[i], outs[i], hip_streams[i]);
+        if (rc == GPR_OK) rc = r;
+    }
+    for (int32_t w = 0; w < n_workers; ++w) {
+        const int r = launch_worker(w)->wait();
+        if (rc == GPR_OK) rc = r;
+    }
+    return rc;
 }
 
 int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_step_out *out, void *hip_stream) {

@@ -164,15 +164,18 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
     // BE:1799-1805: wall check with the safety offset, mover check without, both on noisy reads
     if constexpr (SHAPE == 0) {
         bool lazy_done = false;
-        if constexpr (!Math<RT>::literal) {
-            // throughput mode, as in the step loop: a noisy read is within band_p of the truth, so wherever the noise-free
-            // verdicts have more room than that they stand and the two draws are skipped (exact)
+        {
+            // as in the step loop: a noisy read is within band_p of the truth, so wherever the noise-free verdicts have more room than
+            // that they stand and the two draws are skipped (exact). In parity mode too: a double-precision draw is a hash and two
+            // dependent table loads, and a served reset claim used to cost a wavefront 12 000 clocks
             if (P.eager_noise == 0) {
                 bool w_unc;
                 const bool w_ok = pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_safe, C.band_p, &w_unc);
                 const RT band_pair = (RT)2 * C.band_p, thr2 = C.max_csum_step * C.max_csum_step;
-                const RT md = pair_min_dist<RT, LPE>(p.x, p.y);
-                const bool p_unc = absr(md - thr2) <= (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
+                RT md;  // the smallest squared pair distance
+                if constexpr (Math<RT>::literal) md = pair_min_d2<RT, LPE>(p.x, p.y);
+                else md = pair_min_dist<RT, LPE>(p.x, p.y);
+                const bool p_unc = absr(md - thr2) <= (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair + (RT)1e-12 * thr2;
                 if (__ballot(live & need & (w_unc | p_unc)) == 0ull) {
                     wc = group_any<LPE>(live & !w_ok);
                     mc = group_any<LPE>(live & (md <= thr2));
@@ -1348,8 +1351,16 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
 #undef GPR_WT
 }
 
+// Wavefronts per SIMD the circle / full-grid kernels of up to 4 lanes per env are held to: 4 = 128 registers. The double-precision
+// acceleration-mode kernel needs 148: at 4 it spilled 20 of them to scratch memory (a launch with scratch costs ~2 us more, and the
+// spill traffic sits around the cycle loop), at 3 it spills nothing. Same device, us per env-step of 65 536 envs (scratch/ab_sub.py):
+// one launch per step 50.8 (4) vs 56.6 (3); two sub-batches on two streams -- bench.py's way -- 44.7 vs 41.6. make
+// EXTRA=-DGPR_LITERAL_WAVES=4 builds the other one. (Jerk mode fits 128 registers without spills.)
+#ifndef GPR_LITERAL_WAVES
+#define GPR_LITERAL_WAVES 3
+#endif
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? 4 : 1) k_step(const KParams P) {
+__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? ((Math<RT>::literal && !JERK) ? GPR_LITERAL_WAVES : 4) : 1) k_step(const KParams P) {
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:

@@ -33,32 +33,67 @@ from .benchmark_planning_env import VecBenchmarkPlanningEnv
 
 
 class VecBenchmarkPlanningEnvSubBatched:
-    """``num_envs`` envs as ``num_sub_batches`` ``VecBenchmarkPlanningEnv`` objects over contiguous env ranges. Keywords are
+    """``num_envs`` envs as (up to) ``num_sub_batches`` ``VecBenchmarkPlanningEnv`` objects over contiguous env ranges -- as many as there
+    are streams whose kernels really overlap on this device (``num_sub_batches`` afterwards: what it became). Keywords are
     ``VecBenchmarkPlanningEnv``'s; ``env_id_offset`` is the global id of this object's first env."""
 
     def __init__(self, layout_tiles: np.ndarray, num_movers: int, *args, num_envs: int, num_sub_batches: int = 2, env_id_offset: int = 0,
                  device: str | torch.device = 'cuda', **kwargs) -> None:
         K = int(num_sub_batches)
         assert K >= 1 and num_envs % K == 0, 'num_envs must be a multiple of num_sub_batches (equal sub-batches)'
+        self.device = torch.device(device)
+        self._host_only = bool(kwargs.get('_host_only', False))
+        self.stream_probe = {'requested': K, 'tried': 0, 'rejected': 0}
+        if not self._host_only:
+            if self.device.type != 'cuda':
+                raise RuntimeError('the planar-robotics engine runs on MI355X only (device must be a CUDA/ROCm device); there is no CPU path')
+            if self.device.index is None:
+                self.device = torch.device('cuda', torch.cuda.current_device())
+            self._lib = _native.load()
+            with torch.cuda.device(self.device):
+                # streams first: sub-batches only pay when their kernels really run side by side, so the batch is cut into as many
+                # sub-batches as there are streams that do (a power of two, at most the number asked for)
+                self.streams = self._pick_streams(K)
+            while K > 1 and (K > len(self.streams) or num_envs % K):
+                K //= 2
+            self.streams = self.streams[:K]
         self.num_envs, self.num_sub_batches, self.sub_envs = int(num_envs), K, int(num_envs) // K
         self.env_id_offset = int(env_id_offset)
         self.subs = [VecBenchmarkPlanningEnv(layout_tiles, num_movers, *args, num_envs=self.sub_envs, env_id_offset=self.env_id_offset + k * self.sub_envs,
-                                             device=device, **kwargs) for k in range(K)]
+                                             device=self.device if not self._host_only else device, **kwargs) for k in range(K)]
         s0 = self.subs[0]
-        self.device, self.dtype, self.num_movers, self.obs_dim = s0.device, s0.dtype, s0.num_movers, s0.obs_dim
+        self.dtype, self.num_movers, self.obs_dim = s0.dtype, s0.num_movers, s0.obs_dim
         self.a_max, self.j_max, self.autoreset_mode = s0.a_max, s0.j_max, s0.autoreset_mode
         self.single_observation_space, self.single_action_space = s0.single_observation_space, s0.single_action_space
-        self._host_only = s0._host_only
         if self._host_only:
             return
-        self._lib = s0._lib
         with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(K)]
             self._ready = [torch.cuda.Event() for _ in range(K)]  # the caller's stream has produced sub-batch k's action
             self._done = [torch.cuda.Event() for _ in range(K)]   # sub-batch k's step kernel is through
         self._handles = (C.c_void_p * K)(*[s._handle for s in self.subs])
         self._stream_ptrs = (C.c_void_p * K)(*[st.cuda_stream for st in self.streams])
         self._own_outs = (C.POINTER(_native.GprStepOut) * K)(*[C.pointer(s._out) for s in self.subs])
+
+    def _pick_streams(self, K: int) -> list:
+        """K streams whose kernels really run side by side. The HIP runtime maps streams onto a few hardware queues (four by default) and
+        two streams on one queue execute strictly one after the other (measured: the same two-sub-batch step 38 us on one pair of pool
+        streams, 70 us on another). So every candidate is probed against the streams already chosen (``gpr_streams_overlap``: pairs of
+        150-us single-wavefront kernels) and skipped if it shares a queue with one of them."""
+        chosen, tried = [], 0
+        while len(chosen) < K and tried < 8 * K:
+            cand = torch.cuda.Stream(device=self.device)
+            tried += 1
+            ok = all(st.cuda_stream != cand.cuda_stream for st in chosen)  # (torch hands its pool's streams out again and again)
+            for st in (chosen if ok else []):
+                flag = C.c_int32(0)
+                _native.check(self._lib.gpr_streams_overlap(st.cuda_stream, cand.cuda_stream, C.byref(flag)))
+                ok = ok and bool(flag.value)
+            if ok:
+                chosen.append(cand)
+            else:
+                self.stream_probe['rejected'] += 1
+        self.stream_probe['tried'] = tried
+        return chosen  # (fewer than K: fewer hardware queues than sub-batches asked for -- the caller cuts the batch into fewer)
 
     # ------------------------------------------------------------------------------------------------------------
     def sub(self, k: int) -> VecBenchmarkPlanningEnv:

@@ -138,6 +138,11 @@ int gpr_step(gpr_env *env, const void *action_dev, const gpr_step_out *out, void
 int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_dev, const gpr_step_out *const *outs,
                   void *const *hip_streams);
 
+/* Do kernels on these two HIP streams really run side by side? The runtime maps streams onto a few hardware queues (four by default),
+ * and two streams that land on the same queue execute strictly one after the other -- sub-batches on such a pair gain nothing. Runs
+ * three pairs of 150-us single-wavefront kernels and writes 1 (they overlapped) or 0; both streams are synchronised. */
+int gpr_streams_overlap(void *hip_stream_a, void *hip_stream_b, int32_t *overlap_out);
+
 /* n_steps env-steps in ONE launch, for open-loop rollouts (random / scripted / replayed actions; the benchmark's rollouts): what
  * n_steps calls of gpr_step do, bit for bit (step i draws from call counter tick + i), without a launch, a grid-wide drain and a
  * whole-batch load burst between two steps. action_dev is [n_steps][E][2M] real; EVERY tensor of `out` (final_* included, if set)

@@ -718,7 +718,7 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     assert g['status'] == 'ok' and g['env_steps_per_s'] > 0 and g['minibatch']['env_steps_per_s'] > 0 and g['counters_only']['env_steps_per_s'] > 0
     assert g['bytes_per_rank_per_flush'] > 50 * 2048 * 100
     assert c['distributed'] == {'backend': 'gloo', 'world_size_seen_by_backend': 2}
-    assert line['roofline']['launches_in_flight'] == 2 and line['roofline']['envs_per_launch'] == 2048
+    assert line['roofline']['launches_in_flight'] in (1, 2, 4) and line['roofline']['envs_per_launch'] * line['roofline']['launches_in_flight'] == 4096
     assert line['roofline']['kernel'] == 'gpr::k_step<float, float, 4, false, true, true, 0>'
 
 
@@ -744,6 +744,8 @@ def test_sub_batches_equal_the_whole_batch(gpr, K, kw):
     lay = np.ones((6, 6))
     whole = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E, **kw)
     parts = gpr.VecBenchmarkPlanningEnvSubBatched(lay, M, num_envs=E, num_sub_batches=K, **kw)
+    K = parts.num_sub_batches  # (as many as there are streams that really overlap)
+    assert K >= 2 and parts.stream_probe['tried'] >= K, parts.stream_probe
     ow, _ = whole.reset(seed=5); op, _ = parts.reset(seed=5)
     for k in ow:
         assert torch.equal(ow[k], op[k]), k
