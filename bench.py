@@ -176,6 +176,7 @@ class Pass:
         if sub > 1:
             self.env = gpr.VecBenchmarkPlanningEnvSubBatched(np.ones((tiles, tiles)), self.M, num_sub_batches=sub, **kw)
             self.S = sub = self.env.num_sub_batches  # (as many as there are streams that really overlap on this device)
+            self.stream_probe = self.env.stream_probe
             self.streams = self.env.streams
             if sub == 1:
                 self.env, self.streams = self.env.subs[0], [torch.cuda.current_stream(self.device)]
@@ -279,6 +280,7 @@ def timed(args, rank, local_rank, world, steps=None, warmup=None, **kw):
     # step_us: HIP-event time per env-step of the rank. Every stream runs its n launches back to back, so this is also the average
     # duration of ONE launch as a kernel trace shows it -- S of them (one per sub-batch) in flight at any time
     res = {'wall': wall, 'gpu_ms': gpu_ms, 'reps': reps, 'n_steps': n, 'step_us': gpu_ms * 1e3 / n,
+           'stream_probe': getattr(p.env, 'stream_probe', None) if p.S > 1 else getattr(p, 'stream_probe', None),
            'sub_batches': p.S, 'envs_per_launch': p.E // p.S,
            'env_steps_per_s': world * p.E * n / wall, 'done_fraction': p.done_fraction(), 'rollout_bytes': p.buf.nbytes}
     p.close()
@@ -428,7 +430,7 @@ def main():
         'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
         'sub_batches': f'{S} sub-batches of {E // S} envs per GPU, one handle + one HIP stream each, {S} launches per env-step issued by one gpr_step_many call',
         'timed_steps': head['n_steps'], 'timed_blocks': head['reps'], 'timed_seconds': head['wall'],
-        'done_fraction_per_step': head['done_fraction'],
+        'done_fraction_per_step': head['done_fraction'], 'stream_probe': head['stream_probe'],
     }
     if backend:
         cfg['distributed'] = backend

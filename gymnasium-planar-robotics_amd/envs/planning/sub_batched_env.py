@@ -79,6 +79,9 @@ class VecBenchmarkPlanningEnvSubBatched:
         two streams on one queue execute strictly one after the other (measured: the same two-sub-batch step 38 us on one pair of pool
         streams, 70 us on another). So every candidate is probed against the streams already chosen (``gpr_streams_overlap``: pairs of
         150-us single-wavefront kernels) and skipped if it shares a queue with one of them."""
+        import os
+        if os.environ.get('GPR_NO_STREAM_PROBE') == '1':  # (profiling runs under a counter-collecting tool, which serialises every launch)
+            return [torch.cuda.Stream(device=self.device) for _ in range(K)]
         chosen, tried = [], 0
         while len(chosen) < K and tried < 8 * K:
             cand = torch.cuda.Stream(device=self.device)

@@ -1,5 +1,5 @@
 # every kernel of the engine on its BASELINE.json configuration, a few dozen launches each: the workload the round's rocprofv3
-# passes (scratch/profile_round2.sh) run. Prints nothing the profiles need; the kernel names identify the workloads.
+# passes (scratch/profile_round3.sh) run. Prints nothing the profiles need; the kernel names identify the workloads.
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
 import gymnasium_planar_robotics_amd as gpr
@@ -71,7 +71,7 @@ if 'holes' in which:
     for i in range(N): env.step_into(acts[i % 8], env._out)
     torch.cuda.synchronize(); env.close()
 if 'push' in which: pushing(65536); pushing(4096)
-if 'push2' in which and hasattr(gpr.VecBenchmarkPushingEnv, 'supports_two_movers'): pushing(65536, num_movers=2); pushing(4096, num_movers=2)
+if 'push2' in which: pushing(65536, num_movers=2); pushing(4096, num_movers=2)
 if 'views' in which: parallel(32768, 16, 10)
 if 'ops' in which: operators()
 if 'stepn' in which: rollout(65536, 4, 6); rollout(8192, 4, 6)
