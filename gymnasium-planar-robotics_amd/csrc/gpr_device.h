@@ -120,12 +120,11 @@ template <typename ST, typename RT> __device__ __forceinline__ void store2(void 
         __builtin_memcpy(&bits, &o, 8);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(static_cast<ST *>(base) + idx), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        unsigned long long b0, b1;
-        __builtin_memcpy(&b0, &o.x, 8);
-        __builtin_memcpy(&b1, &o.y, 8);
-        unsigned long long *d = reinterpret_cast<unsigned long long *>(static_cast<ST *>(base) + idx);
-        __hip_atomic_store(d, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(d + 1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ONE 16-byte store (two 8-byte write-through ones were counted -- and written -- as two partial sectors: the f64 kernel's
+        // WRITE_SIZE was twice its algorithmic bytes, profiles/round3_pmc_summary.txt); idx is even: 16-byte aligned. A plain store:
+        // the write-through form of this width exists only as inline assembly, whose register hazards the compiler cannot see.
+        typedef double D2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<D2 *>(static_cast<ST *>(base) + idx) = D2{(double)o.x, (double)o.y};
     }
 #endif
 }

@@ -187,8 +187,14 @@ __device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT>
 //   * the relative velocity at a contact point along n / t is n.(vo - vm) + wo (ro x n) - wm (rm x n): the lever arms
 //     themselves are never stored, the products with the inverse masses / inertias are formed once per cycle.
 // Equal to push_cycle up to float rounding (tests/test_gpu_pushing.py holds the float build to the oracle through it).
+// POSITIONS ARE DISPLACEMENTS. A body's x, y here are its displacement since the start of the env-step (at most 8 cm: float ulp 7e-9 m) and
+// rel0[i] is object - mover i at the step's start, formed once in double: the geometry only ever needs object - mover. Summing the
+// 1e-3-sized per-cycle increments onto ~0.4 m positions in float instead put 3e-8 m of rounding into every cycle, and a contact
+// manifold changes discretely (a vertex enters or leaves a face, the axis of least overlap switches) wherever such an error decides:
+// the float build then pushes the 10 g object one cycle earlier or later than the fp64 oracle -- the "events" of tests/test_gpu_pushing.py.
 template <int NM>
-__device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float dt, Body<float> (&mv)[NM], Body<float> &o, const R2<float> (&u)[NM]) {
+__device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float dt, Body<float> (&mv)[NM], Body<float> &o, const R2<float> (&u)[NM],
+                                                const R2<float> (&rel0)[NM]) {
     // 1. external forces
     const float w_gain = dt * Q.Kr * Q.inv_Im, w_den = __builtin_amdgcn_rcpf(1.f + dt * Q.Dr * Q.inv_Im);
 #pragma unroll
@@ -224,7 +230,7 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
         const Body<float> &m = mv[i];
         Pair &q = pr[i];
         q.np = 0; q.npw = 0; q.nx = 0.f; q.ny = 0.f;
-        const float dx = o.x - m.x, dy = o.y - m.y;
+        const float dx = rel0[i].x + (o.x - m.x), dy = rel0[i].y + (o.y - m.y);
         const bool in_range = !(__builtin_fmaf(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
         if (__ballot(in_range) == 0ull) continue;
         if (!have_o) { Math<float>::sincos_(o.th, so, co); have_o = true; }
@@ -627,6 +633,23 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
         Body<RT> m[NM];
 #pragma unroll
         for (int i = 0; i < NM; ++i) m[i] = Body<RT>{p[i].x, p[i].y, rot[i].x, v[i].x, v[i].y, rot[i].y};
+        // throughput (float) mode: the bodies' x, y are DISPLACEMENTS since the start of the step (see push_cycle_fast); base_* = the
+        // positions the step starts from, rel0 = object - mover there (formed in double). The double builds keep absolute positions.
+        R2<RT> base_m[NM], base_o{(RT)0, (RT)0};
+        R2<float> rel0[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) { base_m[i] = R2<RT>{(RT)0, (RT)0}; rel0[i] = R2<float>{0.f, 0.f}; }
+        if constexpr (!Math<RT>::literal) {
+            base_o = R2<RT>{o.x, o.y};
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                base_m[i] = R2<RT>{m[i].x, m[i].y};
+                rel0[i] = R2<float>{(float)((double)o.x - (double)m[i].x), (float)((double)o.y - (double)m[i].y)};
+                m[i].x = (RT)0; m[i].y = (RT)0;
+            }
+            o.x = (RT)0; o.y = (RT)0;
+        }
+        auto mover_xy = [&](int i) { return R2<RT>{base_m[i].x + m[i].x, base_m[i].y + m[i].y}; };  // absolute position of mover i
         bool frozen = reset_first;
         const bool eager = P.eager_noise != 0;
         const RT band_pair = (RT)2 * C.band_p;
@@ -663,7 +686,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
             // cycle out (the votes inside push_cycle then only count the envs that still move, as they should)
             if (!frozen) {
                 if constexpr (Math<RT>::literal) push_cycle<RT, NM>(Q, C.dt, m, o, qacc);
-                else push_cycle_fast<NM>(Q, C.dt, m, o, qacc);
+                else push_cycle_fast<NM>(Q, C.dt, m, o, qacc, rel0);
 #pragma unroll
                 for (int i = 0; i < NM; ++i) acc[i] = qacc[i];
             }
@@ -671,34 +694,38 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 bool wi;
+                const R2<RT> pm = mover_xy(i);
                 if constexpr (NOISE) {
                     bool unc;
-                    wi = !pos_valid_circle<RT, FULL, true>(T, P, m[i].x, m[i].y, cw_step, C.band_p, &unc);
+                    wi = !pos_valid_circle<RT, FULL, true>(T, P, pm.x, pm.y, cw_step, C.band_p, &unc);
                     if (eager | (__ballot(unc & !frozen) != 0ull)) {
-                        const R2<RT> pw = noisy<RT, true>(R2<RT>{m[i].x, m[i].y}, C.sig_p, key[i], 3u * (uint32_t)cyc + 1u);
+                        const R2<RT> pw = noisy<RT, true>(pm, C.sig_p, key[i], 3u * (uint32_t)cyc + 1u);
                         wi = !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
                     }
                 } else {
-                    wi = !pos_valid_circle<RT, FULL>(T, P, m[i].x, m[i].y, cw_step);
+                    wi = !pos_valid_circle<RT, FULL>(T, P, pm.x, pm.y, cw_step);
                 }
                 w |= wi;
             }
             if constexpr (NM > 1) {
                 RT d;
-                hit = pair_hit2<RT>(C, R2<RT>{m[0].x, m[0].y}, R2<RT>{m[1].x, m[1].y}, &d);
+                const R2<RT> pm0 = mover_xy(0), pm1 = mover_xy(NM - 1);
+                hit = pair_hit2<RT>(C, pm0, pm1, &d);
                 if constexpr (NOISE) {
                     if (eager | (__ballot((absr(d - pair_thr) <= pair_band) & !frozen) != 0ull)) {
-                        const R2<RT> q0 = noisy<RT, true>(R2<RT>{m[0].x, m[0].y}, C.sig_p, key[0], 3u * (uint32_t)cyc + 2u);
-                        const R2<RT> q1 = noisy<RT, true>(R2<RT>{m[1].x, m[1].y}, C.sig_p, key[1], 3u * (uint32_t)cyc + 2u);
+                        const R2<RT> q0 = noisy<RT, true>(pm0, C.sig_p, key[0], 3u * (uint32_t)cyc + 2u);
+                        const R2<RT> q1 = noisy<RT, true>(pm1, C.sig_p, key[NM - 1], 3u * (uint32_t)cyc + 2u);
                         hit = pair_hit2<RT>(C, q0, q1);
                     }
                 }
             }
             if (!frozen) { wc = w; mc = hit; frozen = w | hit; }  // BE:1904-1905
         }
+        o.x = base_o.x + o.x; o.y = base_o.y + o.y;  // (float mode: back to absolute positions)
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            p[i] = R2<RT>{stored<ST, RT>(m[i].x), stored<ST, RT>(m[i].y)}; v[i] = R2<RT>{stored<ST, RT>(m[i].vx), stored<ST, RT>(m[i].vy)};
+            const R2<RT> pm = mover_xy(i);
+            p[i] = R2<RT>{stored<ST, RT>(pm.x), stored<ST, RT>(pm.y)}; v[i] = R2<RT>{stored<ST, RT>(m[i].vx), stored<ST, RT>(m[i].vy)};
             rot[i] = R2<RT>{stored<ST, RT>(m[i].th), stored<ST, RT>(m[i].w)};
             acc[i] = R2<RT>{stored<ST, RT>(acc[i].x), stored<ST, RT>(acc[i].y)};
         }

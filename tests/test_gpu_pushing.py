@@ -101,11 +101,12 @@ def test_step_reset_vs_oracle(gpr, oracle, precision, kw):
             # The fp64 build has no such events and pins the algorithm at 1e-9.
             # (with two movers the same event shows in the velocity of the mover that is in contact). An event is a deviation
             # beyond the tolerance the non-events are then held to: scratch/push_err.py measures, over 137 000 env-steps of this
-            # workload, mover velocities off by more than 1e-4 in 0.01 % (one mover) / 0.03 % (two movers) of the env-steps
-            # and by more than 5e-3 in 0.007 % -- a continuum of event sizes, not two classes with a gap between them.
+            # workload, mover velocities off by more than 1e-4 in 0.005 % (one mover) / 0.008 % (two movers) of the env-steps (round 2:
+            # 0.011 % / 0.026 %, before the float build integrated displacements) and object velocities off by more than 5e-3 in 0.04 % /
+            # 0.014 % (0.085 % / 0.092 %) -- a continuum of event sizes, not two classes with a gap between them.
             verr = np.abs(_g(genv.vel) - oenv.vel).max(axis=1)
             event = (oerr[:, 3:5].max(axis=1) > 50 * tol) | (verr > tol)
-            assert event.mean() < 0.02 and oerr[:, 3:5].max() < 0.05 and oerr[:, :2].max() < 2e-3, (step, event.mean(), oerr.max(axis=0))
+            assert event.mean() < 0.01 and oerr[:, 3:5].max() < 0.05 and oerr[:, :2].max() < 2e-3, (step, event.mean(), oerr.max(axis=0))
             assert np.abs(_g(obs['observation'])[ok] - o['observation'][ok]).max() < 5e-3, step
             worst = max(worst, float(oerr[:, 3:5].max()))
             ok = ok & ~event
