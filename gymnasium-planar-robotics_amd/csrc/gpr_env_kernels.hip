@@ -1360,7 +1360,11 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
 #define GPR_LITERAL_WAVES 3
 #endif
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
-__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? ((Math<RT>::literal && !JERK) ? GPR_LITERAL_WAVES : 4) : 1) k_step(const KParams P) {
+#ifndef GPR_BOX_WAVES
+#define GPR_BOX_WAVES 1
+#endif
+__global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? ((Math<RT>::literal && !JERK) ? GPR_LITERAL_WAVES : 4)
+                                         : ((SHAPE == 1 && FULL && !Math<RT>::literal) ? GPR_BOX_WAVES : 1)) k_step(const KParams P) {
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:
