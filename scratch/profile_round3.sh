@@ -15,6 +15,7 @@ echo trace_bench variants done
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_all -- python scratch/prof_workloads.py > $O/trace_all.log 2> $O/trace_all.err
 echo trace_all done
 export GPR_NO_STREAM_PROBE=1   # (counter collection serialises the launches: keep the launch shapes of the unprofiled run)
+export GPR_LAUNCH_THREADS=0     # (... and every launch on the calling thread: one f64 FETCH_SIZE pass with launch workers never came back)
 S="--steps 40 --warmup 60 --no-cpu-baseline --no-extras --min-seconds 0"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 for cfg in "s4:--sub-batches 4" "s1:--sub-batches 1" "f64:--sub-batches 4 --precision f64"; do
