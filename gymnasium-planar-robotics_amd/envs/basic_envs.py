@@ -259,6 +259,18 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # ------------------------------------------------------------------------------------------------------------
+    # the template's extension hooks (BE:1952-1986)
+    # ------------------------------------------------------------------------------------------------------------
+    def _step_callback(self, action: torch.Tensor) -> None:
+        """Called by ``step()`` with the batched action right before the step kernel is launched (BE:1876, 1960-1966): a subclass may
+        use it for host-side bookkeeping per call. The reference's other two hooks run INSIDE the 40-cycle loop of one env
+        (``_mujoco_step_callback`` BE:1881, ``_check_for_other_collisions_callback`` BE:1903) and have no Python counterpart here:
+        the loop lives in the kernel. What they are used for in the two benchmark envs is in the kernel (the per-cycle control,
+        PL:420-450 / PU:419-455); both envs leave the collision hook at its default (no other collision). Static obstacles are
+        expressed as missing tiles of ``layout_tiles`` (tile granularity): a mover reaching over one is a wall collision."""
+        return None
+
+    # ------------------------------------------------------------------------------------------------------------
     # engine additions with no reference counterpart: resumable random streams, checkpoints, episode counters
     # ------------------------------------------------------------------------------------------------------------
     def get_rng_state(self) -> tuple[int, int]:

@@ -210,6 +210,7 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         assert tuple(action.shape) == (self.num_envs, 2 * self.num_movers), 'action dim != action_space dim'
         if action.dtype != self.dtype or action.device != self.device or not action.is_contiguous():
             action = action.to(device=self.device, dtype=self.dtype).contiguous()
+        self._step_callback(action)  # BE:1876
         with torch.cuda.device(self.device):
             _native.check(self._lib.gpr_push_step(self._handle, action.data_ptr(), C.byref(self._out), self._stream()), self._handle)
         info = self._info_dict()
