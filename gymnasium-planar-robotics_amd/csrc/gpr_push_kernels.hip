@@ -300,16 +300,12 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
         }
     }
     // 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points
-    bool in_impulse_space = false;
-    if constexpr (NM == 1) in_impulse_space = any_contact & (pr[0].npw <= 2);
-    if (in_impulse_space) {
-        // One mover, at most two points in any env of the wavefront (the usual face-to-face push): the same Gauss-Seidel sweeps on
-        // the IMPULSES. With b = J V (the relative velocities at the points before any impulse) and A = J M^-1 J^T (formed once per
-        // cycle: n.n = t.t = 1, n.t = 0, the lever-arm products are there) the relative velocity along a row is b + A lambda, an
-        // update is three fma's on the other rows' impulses instead of re-deriving it from six body velocities and pushing the
-        // impulse back into them (14 instead of 35 instructions per point and sweep); the bodies take the summed impulses at the end.
-        Body<float> &m = mv[0];
-        Pair &q = pr[0];
+    // One pair in contact per env, at most two points in any env of the wavefront (the usual face-to-face push): the same Gauss-Seidel
+    // sweeps on the IMPULSES. With b = J V (the relative velocities at the points before any impulse) and A = J M^-1 J^T (formed once per
+    // cycle: n.n = t.t = 1, n.t = 0, the lever-arm products are there) the relative velocity along a row is b + A lambda, an update is
+    // three fma's on the other rows' impulses instead of re-deriving it from six body velocities and pushing the impulse back into them
+    // (14 instead of 35 instructions per point and sweep); the bodies take the summed impulses at the end.
+    auto impulse_solve = [&](Body<float> &m, const Pair &q) __attribute__((always_inline)) {
         const float nx = q.nx, ny = q.ny;
         const bool two = q.np > 1;
         const float dvx = o.vx - m.vx, dvy = o.vy - m.vy, dvn = __builtin_fmaf(dvx, nx, dvy * ny), dvt = __builtin_fmaf(dvy, nx, -(dvx * ny));
@@ -354,6 +350,46 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
             dwo = __builtin_fmaf(jn1, q.won[1], __builtin_fmaf(jt1, q.wot[1], dwo));
         }
         m.w -= dwm; o.w += dwo;
+    };
+    bool in_impulse_space = false;
+    if constexpr (NM == 1) {
+        in_impulse_space = any_contact & (pr[0].npw <= 2);
+        if (in_impulse_space) impulse_solve(mv[0], pr[0]);
+    } else {
+        // Two movers: the sweeps visit mover 0's points, then mover 1's -- and an env in which only ONE of the two pairs touches has an
+        // empty half in every sweep: the one-pair solve above is the same computation. It applies when no env of the wavefront has both
+        // pairs in contact (with 4 envs per wavefront at 4 096 envs: practically always). Which pair is per lane: operands selected, the
+        // mover's velocity written back to the selected mover. (A pair whose block was skipped, or whose second slot was never filled,
+        // holds nothing: zeros are selected there.)
+        const bool ran0 = pr[0].npw > 0, ran1 = pr[NM - 1].npw > 0;  // (wave-uniform)
+        const int npw = pr[0].npw > pr[NM - 1].npw ? pr[0].npw : pr[NM - 1].npw;
+        in_impulse_space = any_contact & (npw <= 2) & (__ballot((pr[0].np > 0) & (pr[NM - 1].np > 0)) == 0ull);
+        if (in_impulse_space) {
+            if (ran0 & !ran1) impulse_solve(mv[0], pr[0]);
+            else if (ran1 & !ran0) impulse_solve(mv[NM - 1], pr[NM - 1]);
+            else {
+                const Pair &a = pr[0], &b = pr[NM - 1];
+                const bool sel = b.np > 0;  // this env's touching pair is mover 1's (neither touches: pair 0, np = 0, nothing happens)
+                const bool a1 = a.npw > 1, b1 = b.npw > 1;
+                Pair q;
+                q.np = sel ? b.np : a.np; q.npw = npw; q.nx = sel ? b.nx : a.nx; q.ny = sel ? b.ny : a.ny;
+#define GPR_SEL0(f) q.f[0] = sel ? b.f[0] : a.f[0]
+#define GPR_SEL1(f) q.f[1] = sel ? (b1 ? b.f[1] : 0.f) : (a1 ? a.f[1] : 0.f)
+                GPR_SEL0(rmn); GPR_SEL0(ron); GPR_SEL0(rmt); GPR_SEL0(rot_); GPR_SEL0(wmn); GPR_SEL0(won); GPR_SEL0(wmt); GPR_SEL0(wot);
+                GPR_SEL0(inv_kn); GPR_SEL0(inv_kt); GPR_SEL0(bias);
+                GPR_SEL1(rmn); GPR_SEL1(ron); GPR_SEL1(rmt); GPR_SEL1(rot_); GPR_SEL1(wmn); GPR_SEL1(won); GPR_SEL1(wmt); GPR_SEL1(wot);
+                GPR_SEL1(inv_kn); GPR_SEL1(inv_kt); GPR_SEL1(bias);
+#undef GPR_SEL0
+#undef GPR_SEL1
+                Body<float> m = mv[0];
+                m.vx = sel ? mv[NM - 1].vx : mv[0].vx; m.vy = sel ? mv[NM - 1].vy : mv[0].vy; m.w = sel ? mv[NM - 1].w : mv[0].w;
+                impulse_solve(m, q);
+                mv[0].vx = sel ? mv[0].vx : m.vx; mv[0].vy = sel ? mv[0].vy : m.vy; mv[0].w = sel ? mv[0].w : m.w;
+                mv[NM - 1].vx = sel ? m.vx : mv[NM - 1].vx; mv[NM - 1].vy = sel ? m.vy : mv[NM - 1].vy; mv[NM - 1].w = sel ? m.w : mv[NM - 1].w;
+            }
+        }
+    }
+    if (in_impulse_space) {
     } else if (any_contact) {  // (wave-uniform)
         for (int it = 0; it < 4; ++it) {
 #pragma unroll
