@@ -160,7 +160,7 @@ class Pass:
     """One timed configuration on this rank: `envs` envs stepped as `sub` sub-batches (1: one handle, one launch per step)."""
 
     def __init__(self, args, rank, local_rank, world, *, envs, std_noise=1e-5, precision=None, movers=None, tiles=None, flush=None, sub=1,
-                 collision_params=None):
+                 collision_params=None, layout=None, learn_jerk=False):
         import numpy as np
         import torch
 
@@ -172,21 +172,24 @@ class Pass:
         self.M, self.E, self.S = movers or args.movers, envs, sub
         tiles = tiles or args.tiles
         precision = precision or args.precision
-        kw = dict(num_envs=envs, device=self.device, std_noise=std_noise, precision=precision, env_id_offset=rank * envs, collision_params=collision_params)
+        kw = dict(num_envs=envs, device=self.device, std_noise=std_noise, precision=precision, env_id_offset=rank * envs, collision_params=collision_params,
+                  learn_jerk=learn_jerk)
+        lay = np.ones((tiles, tiles)) if layout is None else layout
         if sub > 1:
-            self.env = gpr.VecBenchmarkPlanningEnvSubBatched(np.ones((tiles, tiles)), self.M, num_sub_batches=sub, **kw)
+            self.env = gpr.VecBenchmarkPlanningEnvSubBatched(lay, self.M, num_sub_batches=sub, **kw)
             self.S = sub = self.env.num_sub_batches  # (as many as there are streams that really overlap on this device)
             self.stream_probe = self.env.stream_probe
             self.streams = self.env.streams
             if sub == 1:
                 self.env, self.streams = self.env.subs[0], [torch.cuda.current_stream(self.device)]
         else:
-            self.env = gpr.VecBenchmarkPlanningEnv(np.ones((tiles, tiles)), self.M, **kw)
+            self.env = gpr.VecBenchmarkPlanningEnv(lay, self.M, **kw)
             self.streams = [torch.cuda.current_stream(self.device)]
         env, M, E, T = self.env, self.M, self.E, T_ROLLOUT
         self.buf = gpr.distributed.RolloutBuffer(T, E, M, env.obs_dim, dtype=env.dtype, device=self.device)
         gen = torch.Generator(device=self.device).manual_seed(1234 + rank)
-        ring = (torch.rand(T, E, 2 * M, device=self.device, generator=gen, dtype=torch.float32) * (2 * env.a_max) - env.a_max).to(env.dtype)
+        lim = env.j_max if learn_jerk else env.a_max
+        ring = (torch.rand(T, E, 2 * M, device=self.device, generator=gen, dtype=torch.float32) * (2 * lim) - lim).to(env.dtype)
         self.buf['action'].copy_(ring)  # the rollout buffer's action field doubles as the action ring
         self.outs, self.actions = [], []
         for t in range(T):
