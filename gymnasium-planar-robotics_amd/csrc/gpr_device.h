@@ -833,12 +833,6 @@ template <typename RT, bool PLAIN = false> __device__ __forceinline__ R2<RT> cla
     RT t0 = dt * deriv.x + cur.x, t1 = dt * deriv.y + cur.y;  // PL:631
     RT n2 = t0 * t0 + t1 * t1;
     if constexpr (Math<RT>::literal) {
-        // a correctly rounded root is monotone: below max^2 (1 - 1e-12) the norm is below max whatever the last bits -- a wavefront
-        // none of whose lanes is that close takes no root at all (a double sqrt is ~19 instructions; jerk mode clamps twice per cycle)
-        if (__ballot(n2 >= (max_value * max_value) * (RT)(1.0 - 1e-12)) == 0ull) {
-            next.x = t0; next.y = t1;
-            return deriv;  // PL:636-637
-        }
         RT norm = sqrt(n2);  // PL:633
         if (norm >= max_value) {  // PL:634, inclusive
             if constexpr (PLAIN) {
