@@ -402,7 +402,10 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend; 'gloo' + --single-device rehearses N > 1 on one GPU")
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     ap.add_argument('--fail-rank', type=int, default=-1, help='test hook: this rank exits with code 7 before the rendezvous')
+    ap.add_argument('--watchdog', type=float, default=1500.0, help='seconds after which a rank dumps its Python stacks and exits (a HIP call that never returns)')
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.dump_traceback_later(args.watchdog, exit=True)           # a hung run ends with a location instead of a silent kill
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus, args.launch_timeout))  # nothing has touched the GPU in this process

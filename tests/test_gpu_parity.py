@@ -704,7 +704,8 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device', '--envs-per-gpu', '4096',
-                        '--steps', '30', '--warmup', '10', '--min-seconds', '0.02', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+                        '--steps', '30', '--warmup', '10', '--min-seconds', '0.02', '--no-cpu-baseline', '--launch-timeout', '200', '--gather-timeout', '60',
+                        '--watchdog', '180'], env=env, capture_output=True, text=True, timeout=240)   # (a hang ends with the ranks' stacks in stderr)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 30
@@ -730,7 +731,8 @@ def test_bench_dead_rank_fails_fast(gpr):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device', '--envs-per-gpu', '1024',
-                        '--steps', '10', '--warmup', '2', '--no-cpu-baseline', '--fail-rank', '1'], env=env, capture_output=True, text=True, timeout=300)
+                        '--steps', '10', '--warmup', '2', '--no-cpu-baseline', '--fail-rank', '1', '--launch-timeout', '200', '--watchdog', '180'],
+                       env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and time.monotonic() - t0 < 120
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert 'rank 1' in r.stderr
