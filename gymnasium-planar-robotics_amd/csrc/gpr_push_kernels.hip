@@ -192,169 +192,206 @@ __device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT>
 // 1e-3-sized per-cycle increments onto ~0.4 m positions in float instead put 3e-8 m of rounding into every cycle, and a contact
 // manifold changes discretely (a vertex enters or leaves a face, the axis of least overlap switches) wherever such an error decides:
 // the float build then pushes the 10 g object one cycle earlier or later than the fp64 oracle -- the "events" of tests/test_gpu_pushing.py.
+// the contact points of one (mover, object) pair in the throughput form
+struct FastPair {
+    int np, npw;  // contact points of this env's pair; the most of any env of the wavefront (scalar: bounds the slot loops)
+    float nx, ny;
+    float rmn[PUSH_SLOTS], ron[PUSH_SLOTS], rmt[PUSH_SLOTS], rot_[PUSH_SLOTS];  // lever arms x n, x t
+    float wmn[PUSH_SLOTS], won[PUSH_SLOTS], wmt[PUSH_SLOTS], wot[PUSH_SLOTS];   // ... times the inverse inertias
+    float inv_kn[PUSH_SLOTS], inv_kt[PUSH_SLOTS], bias[PUSH_SLOTS], jn[PUSH_SLOTS], jt[PUSH_SLOTS];
+};
+
+// 1. external forces: a mover's actuation and yaw impedance; the object's damping and friction against the tile
+__device__ __forceinline__ void fast_forces_mover(const PushCst<float> &Q, float dt, Body<float> &m, R2<float> u) {
+    const float w_gain = dt * Q.Kr * Q.inv_Im, w_den = __builtin_amdgcn_rcpf(1.f + dt * Q.Dr * Q.inv_Im);
+    m.vx = __builtin_fmaf(dt, u.x, m.vx);
+    m.vy = __builtin_fmaf(dt, u.y, m.vy);
+    m.w = __builtin_fmaf(-w_gain, m.th, m.w) * w_den;
+}
+__device__ __forceinline__ void fast_forces_object(const PushCst<float> &Q, Body<float> &o) {
+    const float vx = o.vx * Q.damp_lin, vy = o.vy * Q.damp_lin, w = o.w * __builtin_amdgcn_rcpf(Q.damp_rot_den);
+    const float sp2 = __builtin_fmaf(vx, vx, vy * vy);
+    const float k = sp2 > Q.fric_dv * Q.fric_dv ? __builtin_fmaf(-Q.fric_dv, __builtin_amdgcn_rsqf(sp2), 1.f) : 0.f;  // (sp - dv) / sp
+    o.vx = vx * k; o.vy = vy * k;
+    const float aw = __builtin_fabsf(w);
+    o.w = aw <= Q.fric_dw ? 0.f : __builtin_copysignf(aw - Q.fric_dw, w);
+}
+
+// 2. contact geometry of the pair (mover m, object), in the mover's frame. Returns whether some env of the wavefront touches (wave-uniform);
+// q.npw stays 0 otherwise and the slots hold nothing. so / co: sine and cosine of the object's yaw, formed on first use (have_o).
+__device__ __forceinline__ bool fast_pair_geometry(const PushCst<float> &Q, const Body<float> &m, const Body<float> &o, R2<float> rel0, float &so, float &co,
+                                                   bool &have_o, float imm, float inv_tc, FastPair &q) {
+    q.np = 0; q.npw = 0; q.nx = 0.f; q.ny = 0.f;
+    const float dx = rel0.x + (o.x - m.x), dy = rel0.y + (o.y - m.y);
+    const bool in_range = !(__builtin_fmaf(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
+    if (__ballot(in_range) == 0ull) return false;
+    if (!have_o) { Math<float>::sincos_(o.th, so, co); have_o = true; }
+    float sm, cm;
+    Math<float>::sincos_(m.th, sm, cm);
+    const float c = __builtin_fmaf(co, cm, so * sm), s = __builtin_fmaf(so, cm, -(co * sm));  // the object's axes in the mover's frame: (c, s), (-s, c)
+    const float lx = __builtin_fmaf(dx, cm, dy * sm), ly = __builtin_fmaf(dy, cm, -(dx * sm)); // the object's centre in the mover's frame
+    const float ac = __builtin_fabsf(c), as = __builtin_fabsf(s);
+    // separating axes in the order of push_cycle: mover x, mover y, object x, object y; the first smallest overlap wins
+    const float ro01 = Q.h * (ac + as);
+    const float d2 = __builtin_fmaf(lx, c, ly * s), d3 = __builtin_fmaf(ly, c, -(lx * s));
+    const float ov0 = (Q.ax + ro01) - __builtin_fabsf(lx), ov1 = (Q.ay + ro01) - __builtin_fabsf(ly);
+    const float ov2 = (__builtin_fmaf(Q.ax, ac, Q.ay * as) + Q.h) - __builtin_fabsf(d2);
+    const float ov3 = (__builtin_fmaf(Q.ax, as, Q.ay * ac) + Q.h) - __builtin_fabsf(d3);
+    const bool touching = in_range & !(__builtin_fminf(__builtin_fminf(ov0, ov1), __builtin_fminf(ov2, ov3)) < 0.f);
+    if (__ballot(touching) == 0ull) return false;
+    float best = ov0, nlx = __builtin_copysignf(1.f, lx), nly = 0.f;  // the normal in the mover's frame, towards the object
+    { const bool t = ov1 < best; best = t ? ov1 : best; nlx = t ? 0.f : nlx; nly = t ? __builtin_copysignf(1.f, ly) : nly; }
+    { const bool t = ov2 < best; best = t ? ov2 : best; nlx = t ? __builtin_copysignf(c, c * d2) : nlx; nly = t ? __builtin_copysignf(s, s * d2) : nly; }
+    { const bool t = ov3 < best; best = t ? ov3 : best; nlx = t ? __builtin_copysignf(s, -(s * d3)) : nlx; nly = t ? __builtin_copysignf(c, c * d3) : nly; }
+    const float nx = __builtin_fmaf(nlx, cm, -(nly * sm)), ny = __builtin_fmaf(nlx, sm, nly * cm);
+    const float rm_n = __builtin_fmaf(Q.ax, __builtin_fabsf(nlx), Q.ay * __builtin_fabsf(nly));
+    const float ro_n = Q.h * (__builtin_fabsf(__builtin_fmaf(nlx, c, nly * s)) + __builtin_fabsf(__builtin_fmaf(nly, c, -(nlx * s))));
+    // candidates: bit k = object vertex k inside the mover, bit 4 + k = mover vertex k inside the object (vertex order of push_cycle)
+    const float hc = Q.h * c, hs = Q.h * s, e1 = hc - hs, e2 = hc + hs;
+    auto in_m = [&](float vx, float vy) { return (__builtin_fabsf(vx) <= Q.ax) & (__builtin_fabsf(vy) <= Q.ay); };
+    const float qxm = -Q.ax - lx, qxp = Q.ax - lx, qym = -Q.ay - ly, qyp = Q.ay - ly;  // mover vertices relative to the object's centre
+    const float qyms = qym * s, qyps = qyp * s, qxms = qxm * s, qxps = qxp * s;
+    auto in_o = [&](float qx, float qy, float qys, float qxs) {
+        return (__builtin_fabsf(__builtin_fmaf(qx, c, qys)) <= Q.h) & (__builtin_fabsf(__builtin_fmaf(qy, c, -qxs)) <= Q.h);
+    };
+    unsigned mask = (in_m(lx - e1, ly - e2) ? 1u : 0u) | (in_m(lx - e2, ly + e1) ? 2u : 0u) | (in_m(lx + e1, ly + e2) ? 4u : 0u) |
+                    (in_m(lx + e2, ly - e1) ? 8u : 0u) | (in_o(qxm, qym, qyms, qxms) ? 16u : 0u) | (in_o(qxm, qyp, qyps, qxms) ? 32u : 0u) |
+                    (in_o(qxp, qyp, qyps, qxps) ? 64u : 0u) | (in_o(qxp, qym, qyms, qxps) ? 128u : 0u);
+    mask = touching ? mask : 0u;
+    const bool lone = touching & (mask == 0u);  // boxes overlap but no vertex is inside the other: one point between the centres
+    const int np_raw = __popc(mask);
+    const int np = lone ? 1 : (np_raw < PUSH_SLOTS ? np_raw : PUSH_SLOTS);
+    q.np = np; q.nx = nx; q.ny = ny;
+    // (one wave-level decision per pair and cycle instead of one per slot and sweep: the loops below are scalar-bounded)
+    const int npw = __ballot(np > 1) == 0ull ? 1 : __ballot(np > 2) == 0ull ? 2 : __ballot(np > 3) == 0ull ? 3 : 4;
+    q.npw = npw;
+#pragma unroll
+    for (int k = 0; k < PUSH_SLOTS; ++k) {
+        if (k >= npw) break;
+        const int idx = mask != 0u ? __builtin_ctz(mask) : 0;
+        mask &= mask - 1u;
+        const bool of_mover = idx >= 4;
+        const float sxf = (idx & 2) ? 1.f : -1.f, syf = ((idx + 1) & 2) ? 1.f : -1.f;
+        // the point in the mover's frame and its depth along n
+        float px = of_mover ? sxf * Q.ax : __builtin_fmaf(-syf, hs, __builtin_fmaf(sxf, hc, lx));
+        float py = of_mover ? syf * Q.ay : __builtin_fmaf(syf, hc, __builtin_fmaf(sxf, hs, ly));
+        const float pn = of_mover ? __builtin_fmaf(px - lx, nlx, (py - ly) * nly) : -__builtin_fmaf(px, nlx, py * nly);
+        float dep = (of_mover ? ro_n : rm_n) + pn;
+        float rmx = __builtin_fmaf(px, cm, -(py * sm)), rmy = __builtin_fmaf(px, sm, py * cm);
+        if (k == 0) { rmx = lone ? 0.5f * dx : rmx; rmy = lone ? 0.5f * dy : rmy; dep = lone ? best : dep; }
+        const float rox = rmx - dx, roy = rmy - dy;
+        const float rmn = __builtin_fmaf(rmx, ny, -(rmy * nx)), ron = __builtin_fmaf(rox, ny, -(roy * nx));
+        const float rmt = __builtin_fmaf(rmx, nx, rmy * ny), rot = __builtin_fmaf(rox, nx, roy * ny);  // r x t with t = (-ny, nx)
+        q.rmn[k] = rmn; q.ron[k] = ron; q.rmt[k] = rmt; q.rot_[k] = rot;
+        q.wmn[k] = rmn * Q.inv_Im; q.won[k] = ron * Q.inv_Io; q.wmt[k] = rmt * Q.inv_Im; q.wot[k] = rot * Q.inv_Io;
+        q.inv_kn[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmn, q.wmn[k], __builtin_fmaf(ron, q.won[k], imm)));
+        q.inv_kt[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmt, q.wmt[k], __builtin_fmaf(rot, q.wot[k], imm)));
+        q.bias[k] = __builtin_fmaxf(dep, 0.f) * inv_tc;
+        q.jn[k] = 0.f; q.jt[k] = 0.f;
+    }
+    return true;
+}
+
+// 3a. sequential impulses of ONE pair with at most two points in any env of the wavefront (the usual face-to-face push): the same
+// Gauss-Seidel sweeps on the IMPULSES. With b = J V (the relative velocities at the points before any impulse) and A = J M^-1 J^T (formed
+// once per cycle: n.n = t.t = 1, n.t = 0, the lever-arm products are there) the relative velocity along a row is b + A lambda, an update is
+// three fma's on the other rows' impulses instead of re-deriving it from six body velocities and pushing the impulse back into them
+// (14 instead of 35 instructions per point and sweep); the bodies take the summed impulses at the end. A lane without contact
+// (q.np == 0) changes nothing.
+__device__ __forceinline__ void fast_impulse_solve(const PushCst<float> &Q, float imm, Body<float> &m, Body<float> &o, const FastPair &q) {
+    const float nx = q.nx, ny = q.ny;
+    const bool two = q.np > 1;
+    const float dvx = o.vx - m.vx, dvy = o.vy - m.vy, dvn = __builtin_fmaf(dvx, nx, dvy * ny), dvt = __builtin_fmaf(dvy, nx, -(dvx * ny));
+    const float bn0 = __builtin_fmaf(o.w, q.ron[0], __builtin_fmaf(-m.w, q.rmn[0], dvn)), bt0 = __builtin_fmaf(o.w, q.rot_[0], __builtin_fmaf(-m.w, q.rmt[0], dvt));
+    const float a_n0t0 = __builtin_fmaf(q.rmn[0], q.wmt[0], q.ron[0] * q.wot[0]);
+    const bool both = q.npw > 1;  // (wave-uniform; slot 1 holds nothing otherwise)
+    float bn1 = 0.f, bt1 = 0.f, a_n1t1 = 0.f, a_n0n1 = 0.f, a_t0t1 = 0.f, a_n0t1 = 0.f, a_t0n1 = 0.f, ikn1 = 0.f, ikt1 = 0.f, bias1 = 0.f;
+    if (both) {
+        bn1 = __builtin_fmaf(o.w, q.ron[1], __builtin_fmaf(-m.w, q.rmn[1], dvn)); bt1 = __builtin_fmaf(o.w, q.rot_[1], __builtin_fmaf(-m.w, q.rmt[1], dvt));
+        a_n1t1 = __builtin_fmaf(q.rmn[1], q.wmt[1], q.ron[1] * q.wot[1]);
+        a_n0n1 = __builtin_fmaf(q.rmn[0], q.wmn[1], __builtin_fmaf(q.ron[0], q.won[1], imm));
+        a_t0t1 = __builtin_fmaf(q.rmt[0], q.wmt[1], __builtin_fmaf(q.rot_[0], q.wot[1], imm));
+        a_n0t1 = __builtin_fmaf(q.rmn[0], q.wmt[1], q.ron[0] * q.wot[1]); a_t0n1 = __builtin_fmaf(q.rmt[0], q.wmn[1], q.rot_[0] * q.won[1]);
+        ikn1 = two ? q.inv_kn[1] : 0.f; ikt1 = two ? q.inv_kt[1] : 0.f;  // an env with one point: its second row stays at zero
+        bias1 = q.bias[1];
+    }
+    float jn0 = 0.f, jt0 = 0.f, jn1 = 0.f, jt1 = 0.f;
+    for (int it = 0; it < 4; ++it) {
+        float r = bn0 + a_n0t0 * jt0;
+        if (both) r = __builtin_fmaf(a_n0t1, jt1, __builtin_fmaf(a_n0n1, jn1, r));
+        jn0 = __builtin_fmaxf((q.bias[0] - r) * q.inv_kn[0], 0.f);
+        r = __builtin_fmaf(a_n0t0, jn0, bt0);
+        if (both) r = __builtin_fmaf(a_t0t1, jt1, __builtin_fmaf(a_t0n1, jn1, r));
+        float lim = Q.mu * jn0;
+        jt0 = __builtin_fminf(__builtin_fmaxf(-r * q.inv_kt[0], -lim), lim);
+        if (both) {
+            r = __builtin_fmaf(a_n1t1, jt1, __builtin_fmaf(a_t0n1, jt0, __builtin_fmaf(a_n0n1, jn0, bn1)));
+            jn1 = __builtin_fmaxf((bias1 - r) * ikn1, 0.f);
+            r = __builtin_fmaf(a_n1t1, jn1, __builtin_fmaf(a_t0t1, jt0, __builtin_fmaf(a_n0t1, jn0, bt1)));
+            lim = Q.mu * jn1;
+            jt1 = __builtin_fminf(__builtin_fmaxf(-r * ikt1, -lim), lim);
+        }
+    }
+    if (q.np == 0) { jn0 = 0.f; jt0 = 0.f; }  // (an env without contact in a wavefront with one)
+    const float jn = jn0 + jn1, jt = jt0 + jt1;
+    const float px = __builtin_fmaf(jn, nx, -(jt * ny)), py = __builtin_fmaf(jn, ny, jt * nx);  // summed impulse on the object; t = (-ny, nx)
+    m.vx = __builtin_fmaf(-px, Q.inv_mm, m.vx); m.vy = __builtin_fmaf(-py, Q.inv_mm, m.vy);
+    o.vx = __builtin_fmaf(px, Q.inv_mo, o.vx); o.vy = __builtin_fmaf(py, Q.inv_mo, o.vy);
+    float dwm = __builtin_fmaf(jn0, q.wmn[0], jt0 * q.wmt[0]), dwo = __builtin_fmaf(jn0, q.won[0], jt0 * q.wot[0]);
+    if (both) {  // (slot 1 holds nothing in a wavefront whose envs all have one point)
+        dwm = __builtin_fmaf(jn1, q.wmn[1], __builtin_fmaf(jt1, q.wmt[1], dwm));
+        dwo = __builtin_fmaf(jn1, q.won[1], __builtin_fmaf(jt1, q.wot[1], dwo));
+    }
+    m.w -= dwm; o.w += dwo;
+}
+
+// 3b. one visit of a pair's points in a sweep, on the body velocities (any number of points, any number of pairs in contact);
+// `mine`: the lane takes part (pair lanes: only the lanes of the pair whose turn it is)
+__device__ __forceinline__ void fast_velocity_rows(const PushCst<float> &Q, Body<float> &m, Body<float> &o, FastPair &q, bool mine = true) {
+    const float nx = q.nx, ny = q.ny;
+    const float nmx = nx * Q.inv_mm, nmy = ny * Q.inv_mm, nox = nx * Q.inv_mo, noy = ny * Q.inv_mo;
+#pragma unroll
+    for (int k = 0; k < PUSH_SLOTS; ++k) {
+        if (k >= q.npw) break;
+        if ((k < q.np) & mine) {
+            float dvx = o.vx - m.vx, dvy = o.vy - m.vy;
+            const float vn = __builtin_fmaf(dvx, nx, __builtin_fmaf(dvy, ny, __builtin_fmaf(o.w, q.ron[k], -(m.w * q.rmn[k]))));
+            const float jn_new = __builtin_fmaxf(__builtin_fmaf(q.bias[k] - vn, q.inv_kn[k], q.jn[k]), 0.f);
+            const float dj = jn_new - q.jn[k];
+            q.jn[k] = jn_new;
+            m.vx = __builtin_fmaf(-dj, nmx, m.vx); m.vy = __builtin_fmaf(-dj, nmy, m.vy); m.w = __builtin_fmaf(-dj, q.wmn[k], m.w);
+            o.vx = __builtin_fmaf(dj, nox, o.vx); o.vy = __builtin_fmaf(dj, noy, o.vy); o.w = __builtin_fmaf(dj, q.won[k], o.w);
+            dvx = o.vx - m.vx; dvy = o.vy - m.vy;
+            const float vt = __builtin_fmaf(dvy, nx, __builtin_fmaf(-dvx, ny, __builtin_fmaf(o.w, q.rot_[k], -(m.w * q.rmt[k]))));
+            const float lim = Q.mu * jn_new;
+            const float jt_new = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-vt, q.inv_kt[k], q.jt[k]), -lim), lim);
+            const float djt = jt_new - q.jt[k];
+            q.jt[k] = jt_new;
+            // t = (-ny, nx)
+            m.vx = __builtin_fmaf(djt, nmy, m.vx); m.vy = __builtin_fmaf(-djt, nmx, m.vy); m.w = __builtin_fmaf(-djt, q.wmt[k], m.w);
+            o.vx = __builtin_fmaf(-djt, noy, o.vx); o.vy = __builtin_fmaf(djt, nox, o.vy); o.w = __builtin_fmaf(djt, q.wot[k], o.w);
+        }
+    }
+}
+
 template <int NM>
 __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float dt, Body<float> (&mv)[NM], Body<float> &o, const R2<float> (&u)[NM],
                                                 const R2<float> (&rel0)[NM]) {
-    // 1. external forces
-    const float w_gain = dt * Q.Kr * Q.inv_Im, w_den = __builtin_amdgcn_rcpf(1.f + dt * Q.Dr * Q.inv_Im);
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        Body<float> &m = mv[i];
-        m.vx = __builtin_fmaf(dt, u[i].x, m.vx);
-        m.vy = __builtin_fmaf(dt, u[i].y, m.vy);
-        m.w = __builtin_fmaf(-w_gain, m.th, m.w) * w_den;
-    }
-    {
-        const float vx = o.vx * Q.damp_lin, vy = o.vy * Q.damp_lin, w = o.w * __builtin_amdgcn_rcpf(Q.damp_rot_den);
-        const float sp2 = __builtin_fmaf(vx, vx, vy * vy);
-        const float k = sp2 > Q.fric_dv * Q.fric_dv ? __builtin_fmaf(-Q.fric_dv, __builtin_amdgcn_rsqf(sp2), 1.f) : 0.f;  // (sp - dv) / sp
-        o.vx = vx * k; o.vy = vy * k;
-        const float aw = __builtin_fabsf(w);
-        o.w = aw <= Q.fric_dw ? 0.f : __builtin_copysignf(aw - Q.fric_dw, w);
-    }
-    // 2. contact geometry per pair (mover i, object), in mover i's frame
-    struct Pair {
-        int np, npw;  // contact points of this env's pair; the most of any env of the wavefront (scalar: bounds the slot loops)
-        float nx, ny;
-        float rmn[PUSH_SLOTS], ron[PUSH_SLOTS], rmt[PUSH_SLOTS], rot_[PUSH_SLOTS];  // lever arms x n, x t
-        float wmn[PUSH_SLOTS], won[PUSH_SLOTS], wmt[PUSH_SLOTS], wot[PUSH_SLOTS];   // ... times the inverse inertias
-        float inv_kn[PUSH_SLOTS], inv_kt[PUSH_SLOTS], bias[PUSH_SLOTS], jn[PUSH_SLOTS], jt[PUSH_SLOTS];
-    };
-    Pair pr[NM];
+    for (int i = 0; i < NM; ++i) fast_forces_mover(Q, dt, mv[i], u[i]);
+    fast_forces_object(Q, o);
+    FastPair pr[NM];
     bool any_contact = false;
     float so = 0.f, co = 1.f;
     bool have_o = false;
     const float imm = Q.inv_mm + Q.inv_mo, inv_tc = __builtin_amdgcn_rcpf(Q.tc);
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        const Body<float> &m = mv[i];
-        Pair &q = pr[i];
-        q.np = 0; q.npw = 0; q.nx = 0.f; q.ny = 0.f;
-        const float dx = rel0[i].x + (o.x - m.x), dy = rel0[i].y + (o.y - m.y);
-        const bool in_range = !(__builtin_fmaf(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
-        if (__ballot(in_range) == 0ull) continue;
-        if (!have_o) { Math<float>::sincos_(o.th, so, co); have_o = true; }
-        float sm, cm;
-        Math<float>::sincos_(m.th, sm, cm);
-        const float c = __builtin_fmaf(co, cm, so * sm), s = __builtin_fmaf(so, cm, -(co * sm));  // the object's axes in the mover's frame: (c, s), (-s, c)
-        const float lx = __builtin_fmaf(dx, cm, dy * sm), ly = __builtin_fmaf(dy, cm, -(dx * sm)); // the object's centre in the mover's frame
-        const float ac = __builtin_fabsf(c), as = __builtin_fabsf(s);
-        // separating axes in the order of push_cycle: mover x, mover y, object x, object y; the first smallest overlap wins
-        const float ro01 = Q.h * (ac + as);
-        const float d2 = __builtin_fmaf(lx, c, ly * s), d3 = __builtin_fmaf(ly, c, -(lx * s));
-        const float ov0 = (Q.ax + ro01) - __builtin_fabsf(lx), ov1 = (Q.ay + ro01) - __builtin_fabsf(ly);
-        const float ov2 = (__builtin_fmaf(Q.ax, ac, Q.ay * as) + Q.h) - __builtin_fabsf(d2);
-        const float ov3 = (__builtin_fmaf(Q.ax, as, Q.ay * ac) + Q.h) - __builtin_fabsf(d3);
-        const bool touching = in_range & !(__builtin_fminf(__builtin_fminf(ov0, ov1), __builtin_fminf(ov2, ov3)) < 0.f);
-        if (__ballot(touching) == 0ull) continue;
-        any_contact = true;
-        float best = ov0, nlx = __builtin_copysignf(1.f, lx), nly = 0.f;  // the normal in the mover's frame, towards the object
-        { const bool t = ov1 < best; best = t ? ov1 : best; nlx = t ? 0.f : nlx; nly = t ? __builtin_copysignf(1.f, ly) : nly; }
-        { const bool t = ov2 < best; best = t ? ov2 : best; nlx = t ? __builtin_copysignf(c, c * d2) : nlx; nly = t ? __builtin_copysignf(s, s * d2) : nly; }
-        { const bool t = ov3 < best; best = t ? ov3 : best; nlx = t ? __builtin_copysignf(s, -(s * d3)) : nlx; nly = t ? __builtin_copysignf(c, c * d3) : nly; }
-        const float nx = __builtin_fmaf(nlx, cm, -(nly * sm)), ny = __builtin_fmaf(nlx, sm, nly * cm);
-        const float rm_n = __builtin_fmaf(Q.ax, __builtin_fabsf(nlx), Q.ay * __builtin_fabsf(nly));
-        const float ro_n = Q.h * (__builtin_fabsf(__builtin_fmaf(nlx, c, nly * s)) + __builtin_fabsf(__builtin_fmaf(nly, c, -(nlx * s))));
-        // candidates: bit k = object vertex k inside the mover, bit 4 + k = mover vertex k inside the object (vertex order of push_cycle)
-        const float hc = Q.h * c, hs = Q.h * s, e1 = hc - hs, e2 = hc + hs;
-        auto in_m = [&](float vx, float vy) { return (__builtin_fabsf(vx) <= Q.ax) & (__builtin_fabsf(vy) <= Q.ay); };
-        const float qxm = -Q.ax - lx, qxp = Q.ax - lx, qym = -Q.ay - ly, qyp = Q.ay - ly;  // mover vertices relative to the object's centre
-        const float qyms = qym * s, qyps = qyp * s, qxms = qxm * s, qxps = qxp * s;
-        auto in_o = [&](float qx, float qy, float qys, float qxs) {
-            return (__builtin_fabsf(__builtin_fmaf(qx, c, qys)) <= Q.h) & (__builtin_fabsf(__builtin_fmaf(qy, c, -qxs)) <= Q.h);
-        };
-        unsigned mask = (in_m(lx - e1, ly - e2) ? 1u : 0u) | (in_m(lx - e2, ly + e1) ? 2u : 0u) | (in_m(lx + e1, ly + e2) ? 4u : 0u) |
-                        (in_m(lx + e2, ly - e1) ? 8u : 0u) | (in_o(qxm, qym, qyms, qxms) ? 16u : 0u) | (in_o(qxm, qyp, qyps, qxms) ? 32u : 0u) |
-                        (in_o(qxp, qyp, qyps, qxps) ? 64u : 0u) | (in_o(qxp, qym, qyms, qxps) ? 128u : 0u);
-        mask = touching ? mask : 0u;
-        const bool lone = touching & (mask == 0u);  // boxes overlap but no vertex is inside the other: one point between the centres
-        const int np_raw = __popc(mask);
-        const int np = lone ? 1 : (np_raw < PUSH_SLOTS ? np_raw : PUSH_SLOTS);
-        q.np = np; q.nx = nx; q.ny = ny;
-        // (one wave-level decision per pair and cycle instead of one per slot and sweep: the loops below are scalar-bounded)
-        const int npw = __ballot(np > 1) == 0ull ? 1 : __ballot(np > 2) == 0ull ? 2 : __ballot(np > 3) == 0ull ? 3 : 4;
-        q.npw = npw;
-#pragma unroll
-        for (int k = 0; k < PUSH_SLOTS; ++k) {
-            if (k >= npw) break;
-            const int idx = mask != 0u ? __builtin_ctz(mask) : 0;
-            mask &= mask - 1u;
-            const bool of_mover = idx >= 4;
-            const float sxf = (idx & 2) ? 1.f : -1.f, syf = ((idx + 1) & 2) ? 1.f : -1.f;
-            // the point in the mover's frame and its depth along n
-            float px = of_mover ? sxf * Q.ax : __builtin_fmaf(-syf, hs, __builtin_fmaf(sxf, hc, lx));
-            float py = of_mover ? syf * Q.ay : __builtin_fmaf(syf, hc, __builtin_fmaf(sxf, hs, ly));
-            const float pn = of_mover ? __builtin_fmaf(px - lx, nlx, (py - ly) * nly) : -__builtin_fmaf(px, nlx, py * nly);
-            float dep = (of_mover ? ro_n : rm_n) + pn;
-            float rmx = __builtin_fmaf(px, cm, -(py * sm)), rmy = __builtin_fmaf(px, sm, py * cm);
-            if (k == 0) { rmx = lone ? 0.5f * dx : rmx; rmy = lone ? 0.5f * dy : rmy; dep = lone ? best : dep; }
-            const float rox = rmx - dx, roy = rmy - dy;
-            const float rmn = __builtin_fmaf(rmx, ny, -(rmy * nx)), ron = __builtin_fmaf(rox, ny, -(roy * nx));
-            const float rmt = __builtin_fmaf(rmx, nx, rmy * ny), rot = __builtin_fmaf(rox, nx, roy * ny);  // r x t with t = (-ny, nx)
-            q.rmn[k] = rmn; q.ron[k] = ron; q.rmt[k] = rmt; q.rot_[k] = rot;
-            q.wmn[k] = rmn * Q.inv_Im; q.won[k] = ron * Q.inv_Io; q.wmt[k] = rmt * Q.inv_Im; q.wot[k] = rot * Q.inv_Io;
-            q.inv_kn[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmn, q.wmn[k], __builtin_fmaf(ron, q.won[k], imm)));
-            q.inv_kt[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmt, q.wmt[k], __builtin_fmaf(rot, q.wot[k], imm)));
-            q.bias[k] = __builtin_fmaxf(dep, 0.f) * inv_tc;
-            q.jn[k] = 0.f; q.jt[k] = 0.f;
-        }
-    }
+    for (int i = 0; i < NM; ++i) any_contact |= fast_pair_geometry(Q, mv[i], o, rel0[i], so, co, have_o, imm, inv_tc, pr[i]);
     // 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points
-    // One pair in contact per env, at most two points in any env of the wavefront (the usual face-to-face push): the same Gauss-Seidel
-    // sweeps on the IMPULSES. With b = J V (the relative velocities at the points before any impulse) and A = J M^-1 J^T (formed once per
-    // cycle: n.n = t.t = 1, n.t = 0, the lever-arm products are there) the relative velocity along a row is b + A lambda, an update is
-    // three fma's on the other rows' impulses instead of re-deriving it from six body velocities and pushing the impulse back into them
-    // (14 instead of 35 instructions per point and sweep); the bodies take the summed impulses at the end.
-    auto impulse_solve = [&](Body<float> &m, const Pair &q) __attribute__((always_inline)) {
-        const float nx = q.nx, ny = q.ny;
-        const bool two = q.np > 1;
-        const float dvx = o.vx - m.vx, dvy = o.vy - m.vy, dvn = __builtin_fmaf(dvx, nx, dvy * ny), dvt = __builtin_fmaf(dvy, nx, -(dvx * ny));
-        const float bn0 = __builtin_fmaf(o.w, q.ron[0], __builtin_fmaf(-m.w, q.rmn[0], dvn)), bt0 = __builtin_fmaf(o.w, q.rot_[0], __builtin_fmaf(-m.w, q.rmt[0], dvt));
-        const float a_n0t0 = __builtin_fmaf(q.rmn[0], q.wmt[0], q.ron[0] * q.wot[0]);
-        const bool both = q.npw > 1;  // (wave-uniform; slot 1 holds nothing otherwise)
-        float bn1 = 0.f, bt1 = 0.f, a_n1t1 = 0.f, a_n0n1 = 0.f, a_t0t1 = 0.f, a_n0t1 = 0.f, a_t0n1 = 0.f, ikn1 = 0.f, ikt1 = 0.f, bias1 = 0.f;
-        if (both) {
-            bn1 = __builtin_fmaf(o.w, q.ron[1], __builtin_fmaf(-m.w, q.rmn[1], dvn)); bt1 = __builtin_fmaf(o.w, q.rot_[1], __builtin_fmaf(-m.w, q.rmt[1], dvt));
-            a_n1t1 = __builtin_fmaf(q.rmn[1], q.wmt[1], q.ron[1] * q.wot[1]);
-            a_n0n1 = __builtin_fmaf(q.rmn[0], q.wmn[1], __builtin_fmaf(q.ron[0], q.won[1], imm));
-            a_t0t1 = __builtin_fmaf(q.rmt[0], q.wmt[1], __builtin_fmaf(q.rot_[0], q.wot[1], imm));
-            a_n0t1 = __builtin_fmaf(q.rmn[0], q.wmt[1], q.ron[0] * q.wot[1]); a_t0n1 = __builtin_fmaf(q.rmt[0], q.wmn[1], q.rot_[0] * q.won[1]);
-            ikn1 = two ? q.inv_kn[1] : 0.f; ikt1 = two ? q.inv_kt[1] : 0.f;  // an env with one point: its second row stays at zero
-            bias1 = q.bias[1];
-        }
-        float jn0 = 0.f, jt0 = 0.f, jn1 = 0.f, jt1 = 0.f;
-        for (int it = 0; it < 4; ++it) {
-            float r = bn0 + a_n0t0 * jt0;
-            if (both) r = __builtin_fmaf(a_n0t1, jt1, __builtin_fmaf(a_n0n1, jn1, r));
-            jn0 = __builtin_fmaxf((q.bias[0] - r) * q.inv_kn[0], 0.f);
-            r = __builtin_fmaf(a_n0t0, jn0, bt0);
-            if (both) r = __builtin_fmaf(a_t0t1, jt1, __builtin_fmaf(a_t0n1, jn1, r));
-            float lim = Q.mu * jn0;
-            jt0 = __builtin_fminf(__builtin_fmaxf(-r * q.inv_kt[0], -lim), lim);
-            if (both) {
-                r = __builtin_fmaf(a_n1t1, jt1, __builtin_fmaf(a_t0n1, jt0, __builtin_fmaf(a_n0n1, jn0, bn1)));
-                jn1 = __builtin_fmaxf((bias1 - r) * ikn1, 0.f);
-                r = __builtin_fmaf(a_n1t1, jn1, __builtin_fmaf(a_t0t1, jt0, __builtin_fmaf(a_n0t1, jn0, bt1)));
-                lim = Q.mu * jn1;
-                jt1 = __builtin_fminf(__builtin_fmaxf(-r * ikt1, -lim), lim);
-            }
-        }
-        if (q.np == 0) { jn0 = 0.f; jt0 = 0.f; }  // (an env without contact in a wavefront with one)
-        const float jn = jn0 + jn1, jt = jt0 + jt1;
-        const float px = __builtin_fmaf(jn, nx, -(jt * ny)), py = __builtin_fmaf(jn, ny, jt * nx);  // summed impulse on the object; t = (-ny, nx)
-        m.vx = __builtin_fmaf(-px, Q.inv_mm, m.vx); m.vy = __builtin_fmaf(-py, Q.inv_mm, m.vy);
-        o.vx = __builtin_fmaf(px, Q.inv_mo, o.vx); o.vy = __builtin_fmaf(py, Q.inv_mo, o.vy);
-        float dwm = __builtin_fmaf(jn0, q.wmn[0], jt0 * q.wmt[0]), dwo = __builtin_fmaf(jn0, q.won[0], jt0 * q.wot[0]);
-        if (both) {  // (slot 1 holds nothing in a wavefront whose envs all have one point)
-            dwm = __builtin_fmaf(jn1, q.wmn[1], __builtin_fmaf(jt1, q.wmt[1], dwm));
-            dwo = __builtin_fmaf(jn1, q.won[1], __builtin_fmaf(jt1, q.wot[1], dwo));
-        }
-        m.w -= dwm; o.w += dwo;
-    };
     bool in_impulse_space = false;
     if constexpr (NM == 1) {
         in_impulse_space = any_contact & (pr[0].npw <= 2);
-        if (in_impulse_space) impulse_solve(mv[0], pr[0]);
+        if (in_impulse_space) fast_impulse_solve(Q, imm, mv[0], o, pr[0]);
     } else {
         // Two movers: the sweeps visit mover 0's points, then mover 1's -- and an env in which only ONE of the two pairs touches has an
         // empty half in every sweep: the one-pair solve above is the same computation. It applies when no env of the wavefront has both
@@ -365,13 +402,13 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
         const int npw = pr[0].npw > pr[NM - 1].npw ? pr[0].npw : pr[NM - 1].npw;
         in_impulse_space = any_contact & (npw <= 2) & (__ballot((pr[0].np > 0) & (pr[NM - 1].np > 0)) == 0ull);
         if (in_impulse_space) {
-            if (ran0 & !ran1) impulse_solve(mv[0], pr[0]);
-            else if (ran1 & !ran0) impulse_solve(mv[NM - 1], pr[NM - 1]);
+            if (ran0 & !ran1) fast_impulse_solve(Q, imm, mv[0], o, pr[0]);
+            else if (ran1 & !ran0) fast_impulse_solve(Q, imm, mv[NM - 1], o, pr[NM - 1]);
             else {
-                const Pair &a = pr[0], &b = pr[NM - 1];
+                const FastPair &a = pr[0], &b = pr[NM - 1];
                 const bool sel = b.np > 0;  // this env's touching pair is mover 1's (neither touches: pair 0, np = 0, nothing happens)
                 const bool a1 = a.npw > 1, b1 = b.npw > 1;
-                Pair q;
+                FastPair q;
                 q.np = sel ? b.np : a.np; q.npw = npw; q.nx = sel ? b.nx : a.nx; q.ny = sel ? b.ny : a.ny;
 #define GPR_SEL0(f) q.f[0] = sel ? b.f[0] : a.f[0]
 #define GPR_SEL1(f) q.f[1] = sel ? (b1 ? b.f[1] : 0.f) : (a1 ? a.f[1] : 0.f)
@@ -383,7 +420,7 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
 #undef GPR_SEL1
                 Body<float> m = mv[0];
                 m.vx = sel ? mv[NM - 1].vx : mv[0].vx; m.vy = sel ? mv[NM - 1].vy : mv[0].vy; m.w = sel ? mv[NM - 1].w : mv[0].w;
-                impulse_solve(m, q);
+                fast_impulse_solve(Q, imm, m, o, q);
                 mv[0].vx = sel ? mv[0].vx : m.vx; mv[0].vy = sel ? mv[0].vy : m.vy; mv[0].w = sel ? mv[0].w : m.w;
                 mv[NM - 1].vx = sel ? m.vx : mv[NM - 1].vx; mv[NM - 1].vy = sel ? m.vy : mv[NM - 1].vy; mv[NM - 1].w = sel ? m.w : mv[NM - 1].w;
             }
@@ -393,39 +430,52 @@ __device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float d
     } else if (any_contact) {  // (wave-uniform)
         for (int it = 0; it < 4; ++it) {
 #pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                Body<float> &m = mv[i];
-                Pair &q = pr[i];
-                const float nx = q.nx, ny = q.ny;
-                const float nmx = nx * Q.inv_mm, nmy = ny * Q.inv_mm, nox = nx * Q.inv_mo, noy = ny * Q.inv_mo;
-#pragma unroll
-                for (int k = 0; k < PUSH_SLOTS; ++k) {
-                    if (k >= q.npw) break;
-                    if (k < q.np) {
-                        float dvx = o.vx - m.vx, dvy = o.vy - m.vy;
-                        const float vn = __builtin_fmaf(dvx, nx, __builtin_fmaf(dvy, ny, __builtin_fmaf(o.w, q.ron[k], -(m.w * q.rmn[k]))));
-                        const float jn_new = __builtin_fmaxf(__builtin_fmaf(q.bias[k] - vn, q.inv_kn[k], q.jn[k]), 0.f);
-                        const float dj = jn_new - q.jn[k];
-                        q.jn[k] = jn_new;
-                        m.vx = __builtin_fmaf(-dj, nmx, m.vx); m.vy = __builtin_fmaf(-dj, nmy, m.vy); m.w = __builtin_fmaf(-dj, q.wmn[k], m.w);
-                        o.vx = __builtin_fmaf(dj, nox, o.vx); o.vy = __builtin_fmaf(dj, noy, o.vy); o.w = __builtin_fmaf(dj, q.won[k], o.w);
-                        dvx = o.vx - m.vx; dvy = o.vy - m.vy;
-                        const float vt = __builtin_fmaf(dvy, nx, __builtin_fmaf(-dvx, ny, __builtin_fmaf(o.w, q.rot_[k], -(m.w * q.rmt[k]))));
-                        const float lim = Q.mu * jn_new;
-                        const float jt_new = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-vt, q.inv_kt[k], q.jt[k]), -lim), lim);
-                        const float djt = jt_new - q.jt[k];
-                        q.jt[k] = jt_new;
-                        // t = (-ny, nx)
-                        m.vx = __builtin_fmaf(djt, nmy, m.vx); m.vy = __builtin_fmaf(-djt, nmx, m.vy); m.w = __builtin_fmaf(-djt, q.wmt[k], m.w);
-                        o.vx = __builtin_fmaf(-djt, noy, o.vx); o.vy = __builtin_fmaf(djt, nox, o.vy); o.w = __builtin_fmaf(djt, q.wot[k], o.w);
-                    }
-                }
-            }
+            for (int i = 0; i < NM; ++i) fast_velocity_rows(Q, mv[i], o, pr[i]);
         }
     }
     // 4. positions with the new velocities
 #pragma unroll
     for (int i = 0; i < NM; ++i) { Body<float> &m = mv[i]; m.x = __builtin_fmaf(dt, m.vx, m.x); m.y = __builtin_fmaf(dt, m.vy, m.y); m.th = __builtin_fmaf(dt, m.w, m.th); }
+    o.x = __builtin_fmaf(dt, o.vx, o.x); o.y = __builtin_fmaf(dt, o.vy, o.y); o.th = __builtin_fmaf(dt, o.w, o.th);
+}
+
+// the value the other lane of this lane's couple holds (lanes 2k, 2k + 1): quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t partner_u32(uint32_t v) { return rot_u32<2, 1>(v); }
+template <typename RT> __device__ __forceinline__ RT partner(RT v) { return rot<2, 1>(v); }
+
+// TWO MOVERS, ONE LANE PER PAIR (k_push<..., PAIR = true>). The two pairs' geometry blocks (~250 instructions each) are where a two-mover
+// cycle spends its time, and in one lane they run one after the other. Here an env's lanes come in couples: the even lane owns mover 0
+// and the pair (mover 0, object), the odd lane mover 1 and its pair; both carry the object. A cycle is then as long as the ONE-mover
+// cycle plus the exchange: the object's new velocity goes from the lane whose pair touched to its partner (three quad_perm moves).
+// Arithmetic and its order are those of push_cycle_fast<2>: with one pair in contact the one-pair impulse-space solve in that pair's lane;
+// otherwise (some env of the wavefront has both pairs touching, or more than two points) the velocity sweeps, mover 0's points, then
+// mover 1's, the object's velocity handed over after every visit.
+__device__ __forceinline__ void push_cycle_pair(const PushCst<float> &Q, float dt, Body<float> &m, Body<float> &o, R2<float> u, R2<float> rel0, bool second) {
+    fast_forces_mover(Q, dt, m, u);
+    fast_forces_object(Q, o);
+    FastPair q;
+    float so = 0.f, co = 1.f;
+    bool have_o = false;
+    const float imm = Q.inv_mm + Q.inv_mo, inv_tc = __builtin_amdgcn_rcpf(Q.tc);
+    if (fast_pair_geometry(Q, m, o, rel0, so, co, have_o, imm, inv_tc, q)) {  // (wave-uniform: some lane of either pair touches)
+        const bool other = partner_u32((uint32_t)q.np) != 0u;                // the partner's pair touches
+        auto from_partner = [&](bool take) {
+            const float vx = partner(o.vx), vy = partner(o.vy), w = partner(o.w);
+            o.vx = take ? vx : o.vx; o.vy = take ? vy : o.vy; o.w = take ? w : o.w;
+        };
+        if ((q.npw <= 2) & (__ballot((q.np > 0) & other) == 0ull)) {
+            fast_impulse_solve(Q, imm, m, o, q);
+            from_partner((q.np == 0) & other);
+        } else {
+            for (int it = 0; it < 4; ++it) {
+                fast_velocity_rows(Q, m, o, q, !second);
+                from_partner(second);
+                fast_velocity_rows(Q, m, o, q, second);
+                from_partner(!second);
+            }
+        }
+    }
+    m.x = __builtin_fmaf(dt, m.vx, m.x); m.y = __builtin_fmaf(dt, m.vy, m.y); m.th = __builtin_fmaf(dt, m.w, m.th);
     o.x = __builtin_fmaf(dt, o.vx, o.x); o.y = __builtin_fmaf(dt, o.vy, o.y); o.th = __builtin_fmaf(dt, o.w, o.th);
 }
 
@@ -622,8 +672,9 @@ template <typename ST, typename RT, int NM> __device__ __forceinline__ void push
     store2<ST, RT>(dg, e * 2, g);
 }
 
-template <typename ST, typename RT, int NM, bool JERK, bool NOISE, bool FULL, bool RESET_ONLY>
+template <typename ST, typename RT, int NM, bool JERK, bool NOISE, bool FULL, bool RESET_ONLY, bool PAIR = false>
 __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<RT> Q, const PushPtrs X) {
+    static_assert(!PAIR || (NM == 2 && !Math<RT>::literal && !JERK && !RESET_ONLY), "pair lanes: the two-mover float step kernel");
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -691,6 +742,59 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
         const RT band_pair = (RT)2 * C.band_p;
         const RT pair_thr = Math<RT>::literal ? C.max_csum_step : C.max_csum_step * C.max_csum_step;
         const RT pair_band = Math<RT>::literal ? band_pair : (RT)2 * C.max_csum_step * band_pair + band_pair * band_pair;
+        if constexpr (PAIR) {
+            // one lane per (mover, object) pair -- see push_cycle_pair: this lane's mover, its action, its noise stream; the object in both
+            const bool second = (threadIdx.x & 1u) != 0u;
+            auto pick = [&](RT a0, RT a1) { return second ? a1 : a0; };
+            Body<RT> mm{pick(m[0].x, m[1].x), pick(m[0].y, m[1].y), pick(m[0].th, m[1].th), pick(m[0].vx, m[1].vx), pick(m[0].vy, m[1].vy), pick(m[0].w, m[1].w)};
+            const R2<RT> am{pick(a[0].x, a[1].x), pick(a[0].y, a[1].y)}, basem{pick(base_m[0].x, base_m[1].x), pick(base_m[0].y, base_m[1].y)};
+            const R2<float> rel0m{second ? rel0[1].x : rel0[0].x, second ? rel0[1].y : rel0[0].y};
+            R2<RT> accm{pick(acc[0].x, acc[1].x), pick(acc[0].y, acc[1].y)};
+            const uint32_t keym = second ? key[1] : key[0];
+            for (int cyc = 0; cyc < P.num_cycles; ++cyc) {
+                R2<RT> vn{mm.vx, mm.vy};
+                if constexpr (NOISE) {
+                    const RT t0 = mm.vx + C.dt * am.x, t1 = mm.vy + C.dt * am.y, vl = C.v_max - C.band_v;
+                    const bool nd = !(t0 * t0 + t1 * t1 < vl * vl) | (vl <= (RT)0);
+                    if (eager | (__ballot(nd & !frozen) != 0ull)) vn = noisy<RT, true>(vn, C.sig_v, keym, 3u * (uint32_t)cyc);
+                }
+                R2<RT> vnext;
+                const R2<RT> qaccm = clamp_dyn<RT>(vn, C.v_max, am, C.dt, C.inv_dt, vnext);
+                if (!frozen) {  // (both lanes of an env are frozen together: the exchanges inside always find their partner)
+                    push_cycle_pair(Q, C.dt, mm, o, qaccm, rel0m, second);
+                    accm = qaccm;
+                }
+                const R2<RT> pm{basem.x + mm.x, basem.y + mm.y};
+                bool wi;
+                if constexpr (NOISE) {
+                    bool unc;
+                    wi = !pos_valid_circle<RT, FULL, true>(T, P, pm.x, pm.y, cw_step, C.band_p, &unc);
+                    if (eager | (__ballot(unc & !frozen) != 0ull)) {
+                        const R2<RT> pw = noisy<RT, true>(pm, C.sig_p, keym, 3u * (uint32_t)cyc + 1u);
+                        wi = !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
+                    }
+                } else {
+                    wi = !pos_valid_circle<RT, FULL>(T, P, pm.x, pm.y, cw_step);
+                }
+                const bool w = wi | (partner_u32(wi ? 1u : 0u) != 0u);
+                RT d;
+                bool hit = pair_hit2<RT>(C, pm, R2<RT>{partner(pm.x), partner(pm.y)}, &d);  // (symmetric in its two points, bit for bit)
+                if constexpr (NOISE) {
+                    if (eager | (__ballot((absr(d - pair_thr) <= pair_band) & !frozen) != 0ull)) {
+                        const R2<RT> qm = noisy<RT, true>(pm, C.sig_p, keym, 3u * (uint32_t)cyc + 2u);
+                        hit = pair_hit2<RT>(C, qm, R2<RT>{partner(qm.x), partner(qm.y)});
+                    }
+                }
+                if (!frozen) { wc = w; mc = hit; frozen = w | hit; }  // BE:1904-1905
+            }
+            // every lane gets both movers back
+            const Body<RT> mo{partner(mm.x), partner(mm.y), partner(mm.th), partner(mm.vx), partner(mm.vy), partner(mm.w)};
+            const R2<RT> acco{partner(accm.x), partner(accm.y)};
+#define GPR_BACK(f) m[0].f = second ? mo.f : mm.f; m[NM - 1].f = second ? mm.f : mo.f
+            GPR_BACK(x); GPR_BACK(y); GPR_BACK(th); GPR_BACK(vx); GPR_BACK(vy); GPR_BACK(w);
+#undef GPR_BACK
+            acc[0] = R2<RT>{second ? acco.x : accm.x, second ? acco.y : accm.y}; acc[NM - 1] = R2<RT>{second ? accm.x : acco.x, second ? accm.y : acco.y};
+        } else {
         for (int cyc = 0; cyc < P.num_cycles; ++cyc) {
             // _mujoco_step_callback (PU:419-455): the same clamp chain as the planning env, on a noisy velocity read, per mover
             // lazy noise as in the planning kernels: a reading is drawn only if some lane's comparison could depend on it
@@ -757,6 +861,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
             }
             if (!frozen) { wc = w; mc = hit; frozen = w | hit; }  // BE:1904-1905
         }
+        }
         o.x = base_o.x + o.x; o.y = base_o.y + o.y;  // (float mode: back to absolute positions)
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
@@ -821,8 +926,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
     }
 }
 
-// log2 of the lanes every env gets: the most (up to 64) that keep the grid within one wavefront per SIMD (see the top of this file)
-static int push_lane_shift(int64_t E) {
+static int push_simds() {
     static int simds = 0;  // (the devices of a node are alike)
     if (simds == 0) {
         int dev = 0;
@@ -830,6 +934,11 @@ static int push_lane_shift(int64_t E) {
         simds = 1024;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
     }
+    return simds;
+}
+// log2 of the lanes every env gets: the most (up to 64) that keep the grid within one wavefront per SIMD (see the top of this file)
+static int push_lane_shift(int64_t E) {
+    const int simds = push_simds();
     if (const char *f = std::getenv("GPR_PUSH_LANES")) {  // experiment knob: lanes per env (a power of two up to 64)
         int sh = 0;
         while ((2 << sh) <= std::atoi(f) && sh < 6) ++sh;
@@ -845,6 +954,18 @@ static hipError_t launch_push3(bool is_reset, const KParams &P, const PushCst<RT
     PushPtrs X = X0;
     // (a reset is short: one lane per env)
     X.lane_shift = is_reset ? 0 : push_lane_shift(P.E);
+    if constexpr (NM == 2 && !Math<RT>::literal && !JERK) {
+        // two movers in float: a lane per (mover, object) pair (push_cycle_pair) while that keeps the grid within two wavefronts per SIMD --
+        // beyond, the SIMDs are busy anyway and the couple's redundant object arithmetic only costs. GPR_PUSH_PAIR=0 / 1: never / always.
+        bool pair = ((2 * P.E + 63) / 64) <= 2 * (int64_t)push_simds();
+        if (const char *f = std::getenv("GPR_PUSH_PAIR")) pair = std::atoi(f) != 0;
+        if (pair && !is_reset) {
+            if (X.lane_shift < 1) X.lane_shift = 1;
+            const unsigned grid = (unsigned)(((P.E << X.lane_shift) + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL((k_push<ST, RT, NM, JERK, NOISE, FULL, false, true>), dim3(grid), dim3(BLOCK), lds, s, P, Q, X);
+            return hipGetLastError();
+        }
+    }
     const unsigned grid = (unsigned)(((P.E << X.lane_shift) + BLOCK - 1) / BLOCK);
     if (is_reset) hipLaunchKernelGGL((k_push<ST, RT, NM, JERK, NOISE, FULL, true>), dim3(grid), dim3(BLOCK), lds, s, P, Q, X);
     else hipLaunchKernelGGL((k_push<ST, RT, NM, JERK, NOISE, FULL, false>), dim3(grid), dim3(BLOCK), lds, s, P, Q, X);
