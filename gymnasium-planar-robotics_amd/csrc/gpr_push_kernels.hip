@@ -12,6 +12,8 @@
 // cycles runs the full contact path 40 times whatever shares its wavefront, and that dependent chain (~600 instructions per cycle at
 // ~6 clocks each for a lone wavefront) is the kernel's duration at every batch size up to one wavefront per SIMD. More wavefronts per
 // SIMD do not hide it, they share the SIMD: 2 per SIMD +30 %, 4 per SIMD +85 % (same script).
+// The two-mover float kernel does better than redundancy with its lanes: k_push<..., PAIR = true> gives each (mover, object) pair a lane
+// of its own (push_cycle_pair below; 4 096 envs: 131 -> 105.5 us), taken while the grid stays within two wavefronts per SIMD.
 //
 // Pinned by the reference: control + clamp (PU:419-448), wall check (BE:426-788), obs / info / reward / terminated (PU:457-607),
 // reset sampling (PU:373-417). The contact physics is the engine's own planar model "gpr-push-v2" (parity unpinned: the
