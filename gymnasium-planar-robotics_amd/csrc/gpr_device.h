@@ -273,6 +273,25 @@ template <int LPE, int D> __device__ __forceinline__ void rot_diff2(float x, flo
 template <int LPE, int D> __device__ __forceinline__ void rot_diff2(double x, double y, double &dx, double &dy) {
     dx = rot<LPE, D>(x) - x; dy = rot<LPE, D>(y) - y;
 }
+// rotations D and D + 1 in ONE block: the sources are not written inside it, so the wait states are paid once for the four subtracts
+#define GPR_ROT_DIFF4(C0, C1)                                                                                            \
+    asm("s_nop 1\n\tv_sub_f32_dpp %0, %4, %4 " C0 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+        "v_sub_f32_dpp %1, %5, %5 " C0 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                    \
+        "v_sub_f32_dpp %2, %4, %4 " C1 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                    \
+        "v_sub_f32_dpp %3, %5, %5 " C1 " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                        \
+        : "=&v"(dx0), "=&v"(dy0), "=&v"(dx1), "=&v"(dy1) : "v"(x), "v"(y))
+template <int LPE, int D> __device__ __forceinline__ void rot_diff4(float x, float y, float &dx0, float &dy0, float &dx1, float &dy1) {
+    if constexpr (LPE == 4 && D == 1) { GPR_ROT_DIFF4("quad_perm:[1,2,3,0]", "quad_perm:[2,3,0,1]"); }
+    else if constexpr (LPE == 16 && D == 1) { GPR_ROT_DIFF4("row_ror:15", "row_ror:14"); }
+    else if constexpr (LPE == 16 && D == 3) { GPR_ROT_DIFF4("row_ror:13", "row_ror:12"); }
+    else if constexpr (LPE == 16 && D == 5) { GPR_ROT_DIFF4("row_ror:11", "row_ror:10"); }
+    else if constexpr (LPE == 16 && D == 7) { GPR_ROT_DIFF4("row_ror:9", "row_ror:8"); }
+    else { rot_diff2<LPE, D>(x, y, dx0, dy0); rot_diff2<LPE, D + 1>(x, y, dx1, dy1); }
+}
+#undef GPR_ROT_DIFF4
+template <int LPE, int D> __device__ __forceinline__ void rot_diff4(double x, double y, double &dx0, double &dy0, double &dx1, double &dy1) {
+    rot_diff2<LPE, D>(x, y, dx0, dy0); rot_diff2<LPE, D + 1>(x, y, dx1, dy1);
+}
 
 // bits of the predicate for the LPE lanes of this lane's env group (bit m = mover m)
 template <int LPE> __device__ __forceinline__ uint32_t group_bits(bool pred) {
@@ -752,8 +771,7 @@ template <typename RT, int LPE, int D> struct PairSweep {
             static_assert(D % 2 == 1 && D + 1 <= LPE / 2, "rotations are taken in pairs");
             typedef RT V2 __attribute__((ext_vector_type(2)));
             RT dx0, dy0, dx1, dy1;
-            rot_diff2<LPE, D>(x, y, dx0, dy0);
-            rot_diff2<LPE, D + 1>(x, y, dx1, dy1);
+            rot_diff4<LPE, D>(x, y, dx0, dy0, dx1, dy1);
             const V2 dx{dx0, dx1}, dy{dy0, dy1};
             const V2 m = __builtin_elementwise_fma(dx, dx, dy * dy);
             const RT mm = __builtin_fminf(m.x, m.y);

@@ -68,9 +68,14 @@ __device__ __forceinline__ Obs<RT> observe(const KParams &P, uint32_t key, uint3
 // draws -- set k of the stream is the k-th sample np_random.uniform hands out: the start loop consumes sets until it accepts one, the
 // goal loop goes on from the next (the reference's two loops share one generator, PL:377 / PL:402). An exhausted stream ends a loop
 // like max_reset_trials does (the last set stands).
-template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE, bool SCRIPT = false>
+// MODE (the shared searches of the 16-lane step kernels, step_body): 0 = the whole reset; 1 = this wavefront's stay with the shared search
+// coop_pass of the env -- trials are claimed from *coop_next, the first valid one is posted to *coop_best, nothing else is touched;
+// 2 = the search is over -- the start is candidate coop_ts, the goal candidate coop_tg -- and the rest of the reset (collision flags,
+// first observation) is formed.
+template <typename ST, typename RT, int LPE, bool NOISE, bool FULL, int SHAPE, bool SCRIPT = false, int MODE = 0>
 __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT> &T, int64_t env_global, int mv, int mvc, bool live,
-                                               bool need, RT c, RT c1, int S, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc) {
+                                               bool need, RT c, RT c1, int S, R2<RT> &p, R2<RT> &g, bool &wc, bool &mc, int coop_pass = 0,
+                                               int *coop_next = nullptr, int *coop_best = nullptr, int coop_ts = 0, int coop_tg = 0) {
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
     const CircleSize<RT> cw_safe = circle_size<RT>(P, (c + C.c_offset_wall) + C.c_offset);  // BE:487 with add_safety_offset=True
@@ -112,7 +117,62 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         }
     };
-    for (int pass = 0; pass < 2; ++pass) {  // 0: start positions (PL:369-385), 1: goals (PL:395-413)
+    // the verdict on this lane group's candidate set member cn of `pass` (wave-cooperative: every lane calls it)
+    auto rejected = [&](int pass, R2<RT> cn) {
+        bool w, hit;
+        if constexpr (SHAPE == 0) {
+            w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                    // PL:379 / PL:403-404
+            hit = live & (pass == 0 ? pair_closer<RT, LPE, false>(cn.x, cn.y, C.max_csum_safe)
+                                    : pair_closer<RT, LPE, true>(cn.x, cn.y, C.min_goal_dist));  // PL:381-383 / PL:407-413
+        } else {
+            const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
+            if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
+            else w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
+            if (pass == 0) {  // a candidate set is axis-aligned: bounding boxes decide, the 16 segment tests per pair only in a sliver
+                bool sure = false, unsure = false;
+                AabbSweep<RT, LPE, 1>::run(cn.x, cn.y, ps0, ps1, sure, unsure);
+                if (__ballot(live & unsure) == 0ull) hit = live & sure;
+                else hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
+            }
+            else hit = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);
+        }
+        return group_any<LPE>(w | hit);
+    };
+    if constexpr (MODE == 1) {
+        // one wavefront's stay with a shared search (all S groups on the same env): rounds of S trials claimed from *coop_next until no
+        // unclaimed trial lies below the best valid one posted in *coop_best; the next claim is made BEFORE the round in hand is evaluated
+        // (its LDS round trip hides behind the round; a claim that turns out to lie above the best trial is simply dropped)
+        const uint32_t key = coop_pass == 0 ? ks : kg;
+        const int max_t = P.max_reset_trials;
+        constexpr int RPC = 2;  // rounds per claim
+        int cl = 0, seen = 0;   // (lane 0) the claim made ahead and the best trial seen with it; judged when its turn comes
+        auto claim = [&]() {
+            if (__lane_id() == 0u) {
+                cl = __hip_atomic_fetch_add(coop_next, RPC * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                seen = __hip_atomic_load(coop_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        claim();
+        for (bool found = false; !found;) {
+            const int b = __builtin_amdgcn_readfirstlane(cl), lim = __builtin_amdgcn_readfirstlane(seen);
+            if (!(b < (lim < max_t ? lim : max_t))) break;  // nothing unclaimed below the best valid trial (or the bound): the search is closed
+            claim();
+            for (int r = 0; r < RPC && !found; ++r) {
+                const int trial = b + r * S + slot;
+                const bool bad = rejected(coop_pass, candidate(key, trial));
+                const unsigned long long seg = (__ballot(need & !bad & (trial < max_t)) >> lead_lane) & set_mask;
+                if (seg != 0ull) {
+                    if (__lane_id() == 0u) __hip_atomic_fetch_min(coop_best, b + r * S + (int)(__builtin_ctzll(seg) / LPE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    found = true;  // (whatever this wavefront has claimed beyond lies above the trial just posted)
+                }
+            }
+        }
+        return Obs<RT>{};
+    }
+    if constexpr (MODE == 2) {
+        if (need) { p = candidate(ks, coop_ts); g = candidate(kg, coop_tg); }
+    }
+    for (int pass = 0; pass < (MODE == 2 ? 0 : 2); ++pass) {  // 0: start positions (PL:369-385), 1: goals (PL:395-413)
         const uint32_t key = pass == 0 ? ks : kg;
         bool pending = need;
         R2<RT> cand = pass == 0 ? p : g;
@@ -121,24 +181,7 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             if (__ballot(pending) == 0ull) break;
             const int trial = base + slot;
             const R2<RT> cn = candidate(key, trial);
-            bool w, hit;
-            if constexpr (SHAPE == 0) {
-                w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                    // PL:379 / PL:403-404
-                hit = live & (pass == 0 ? pair_closer<RT, LPE, false>(cn.x, cn.y, C.max_csum_safe)
-                                        : pair_closer<RT, LPE, true>(cn.x, cn.y, C.min_goal_dist));  // PL:381-383 / PL:407-413
-            } else {
-                const Pose<RT> q{cn.x, cn.y, (RT)1, (RT)0, (RT)0, (RT)0};
-                if constexpr (FULL) w = live & !(wall_reach_full<RT>(C, cn.x, cn.y, cw_box_safe) < cw_box_safe.wx);  // axis-aligned candidate
-                else w = live & !pos_valid_box<RT, false>(T, P, q, ws0, ws1, (RT)0, nullptr);
-                if (pass == 0) {  // a candidate set is axis-aligned: bounding boxes decide, the 16 segment tests per pair only in a sliver
-                    bool sure = false, unsure = false;
-                    AabbSweep<RT, LPE, 1>::run(cn.x, cn.y, ps0, ps1, sure, unsure);
-                    if (__ballot(live & unsure) == 0ull) hit = live & sure;
-                    else hit = live & box_pair_hit<RT, LPE>(q, ps0, ps1, (RT)0, true, nullptr);
-                }
-                else hit = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);
-            }
-            bool bad = group_any<LPE>(w | hit);
+            bool bad = rejected(pass, cn);
             if (SCRIPT && scripted) {  // (every lane went through the votes above; only the bookkeeping differs)
                 if (pending) taken = trial + 1;
                 if (used + trial >= P.n_cand - 1) bad = false;  // the stream's last set stands whatever it is
@@ -313,9 +356,9 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     const long long wt0 = __builtin_amdgcn_s_memtime();
     int wt_clamp = 0, wt_near = 0, wt_served = 0, wt_rows = 0, wt_direct = 0, wt_due = 0, wt_exact = 0;
     long long wt_loop0 = 0, wt_loop1 = 0;
-#define GPR_WT(x) x
+#define GPR_WT(...) __VA_ARGS__
 #else
-#define GPR_WT(x)
+#define GPR_WT(...)
 #endif
     // one raw slice of LDS per wavefront: the velocity-reading rows of the cycle loops, then the staging area of the agent views
     __shared__ __align__(16) unsigned char wave_scratch[BLOCK / 64][WAVE_SCRATCH_BYTES];
@@ -330,9 +373,22 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // (gpr_step_n, MULTI: no queue -- every wavefront resets its own envs at the end of each of its steps, so that wavefronts never
     // wait for each other and a block needs no barrier between two steps)
     __shared__ int reset_count, reset_claimed, waves_through, reset_list[BLOCK];
+    // the block-cooperative search of the 16-lane kernels (see "SERVING THE QUEUE" below), per queue entry: the next unclaimed trial and the
+    // smallest valid trial found so far of the start / goal search, chunks in flight, 1 = someone is forming the reset from the result
+#ifdef GPR_NO_COOP
+    constexpr bool COOP = false;
+#else
+    constexpr bool COOP = !MULTI && LPE == 16;
+#endif
+    constexpr int QCAP = COOP ? BLOCK / LPE : 1;
+    __shared__ int coop_next[2 * QCAP], coop_best[2 * QCAP], coop_pend[QCAP], coop_state[QCAP];
     if constexpr (!MULTI) {
         reset_list[threadIdx.x] = -1;
         if (threadIdx.x == 0) { reset_count = 0; reset_claimed = 0; waves_through = 0; }
+        if constexpr (COOP) {
+            if (threadIdx.x < 2 * QCAP) { coop_next[threadIdx.x] = 0; coop_best[threadIdx.x] = 0x7fffffff; }
+            if (threadIdx.x < QCAP) { coop_pend[threadIdx.x] = 0; coop_state[threadIdx.x] = 0; }
+        }
     }
     bool queued = false;
     auto enqueue = [&](bool reset_only) {
@@ -1237,12 +1293,16 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     constexpr int GROUPS = 64 / LPE;
     GPR_WT(const long long wt1 = __builtin_amdgcn_s_memtime();)
     // one claim: n envs, S lane groups each; lane group gi works for claim slot gi / S on env `renv`
-    auto serve = [&](int n, int S, bool have, int64_t renv, bool rfirst, R2<RT> &rp, R2<RT> &rg) __attribute__((always_inline)) {
+    // (found: the search was run elsewhere -- the block-cooperative form -- and ended with start candidate ts, goal candidate tg)
+    auto serve = [&](int n, int S, bool have, int64_t renv, bool rfirst, R2<RT> &rp, R2<RT> &rg, bool found = false, int ts = 0, int tg = 0)
+                     __attribute__((always_inline)) {
         const int gi = (int)(threadIdx.x & 63) / LPE;
         const bool rlive = have & (mv < M);
         rp = R2<RT>{(RT)0, (RT)0}; rg = R2<RT>{(RT)0, (RT)0};
         bool rwc, rmc;
-        const Obs<RT> ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc);
+        Obs<RT> ro;
+        if (COOP && found) ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE, false, 2>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc, 0, nullptr, nullptr, ts, tg);
+        else ro = group_reset<ST, RT, LPE, NOISE, FULL, SHAPE>(P, T, P.env_id_offset + renv, mv, mvc, rlive, have, c, c1, S, rp, rg, rwc, rmc);
         if (rlive & ((gi & (S - 1)) == 0)) {  // one group of the env's set stores
             const int64_t ridx = renv * (2 * (int64_t)M) + 2 * mvc;
             const R2<RT> zero{(RT)0, (RT)0};
@@ -1301,6 +1361,89 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                 if (mine) { carry->p = hp; carry->g = hg; carry->v = R2<RT>{(RT)0, (RT)0}; carry->acc = R2<RT>{(RT)0, (RT)0}; }
             }
         }
+    } else if constexpr (COOP) {
+        // 16 LANES PER ENV: IDLE WAVEFRONTS JOIN THE SEARCHES STILL RUNNING. A candidate set of 16 movers is valid once in ~45 trials, a
+        // wavefront tries four per round, and the unluckiest reset of a batch needs hundreds: at 4 096 envs (one wavefront per SIMD) the
+        // kernel lasted as long as that one search, run by ONE wavefront while the other three of its block -- of its CU -- had nothing left
+        // to do. The trial a search ends with is the first valid one in trial order, whoever evaluates it. So every search (an entry's
+        // start positions, its goals: two independent searches) hands out its rounds of four trials from a counter in LDS: a wavefront
+        // takes a search nobody has begun if there is one (the block's resets then run side by side, as before), else joins the oldest one
+        // still open, and stays with it -- one atomic add per round -- until no unclaimed trial lies below the best valid one (atomic min)
+        // posted so far. Whoever then sees both searches of an entry closed with nobody at work on them forms the reset from the two
+        // trial numbers (group_reset MODE 2). Closed stays closed (the counter only grows, the best only shrinks), and a wavefront
+        // counts as at work from before its first claim: one that claims after somebody saw "closed" gets a round at or above the best
+        // trial and leaves, one that claimed before is seen at work or has posted already.
+        auto ld = [](const int *a) { return __hip_atomic_load(a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int max_t = P.max_reset_trials;
+        GPR_WT(long long ct_scan = 0, ct_sess = 0, ct_form = 0; int cn_poll = 0, cn_sess = 0, cn_help = 0;)
+        for (;;) {
+            int act = 0, sel = 0;  // act: 0 nothing to do right now, 1 join search `sel` (2 * entry + pass), 2 form the reset of entry `sel`, 3 through
+            GPR_WT(const long long ct0 = __builtin_amdgcn_s_memtime();)
+            {
+                // one look at the whole queue: lane i reads entry i (the counters before the "at work" count, see above), ballots decide
+                const int lane = (int)(threadIdx.x & 63), li = lane < QCAP ? lane : 0;
+                const bool all_through = ld(&waves_through) == BLOCK / 64;  // (read before the count: nothing is queued after it was seen set)
+                const int cnt = __hip_atomic_load(&reset_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int st = __hip_atomic_load(&coop_state[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int b0 = __hip_atomic_load(&coop_best[2 * li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int b1 = __hip_atomic_load(&coop_best[2 * li + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int n0 = __hip_atomic_load(&coop_next[2 * li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int n1 = __hip_atomic_load(&coop_next[2 * li + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the counters first, then who is at work
+                const int pd = __hip_atomic_load(&coop_pend[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool mine = (lane < QCAP) & (lane < cnt) & (st == 0);
+                const bool o0 = mine & (n0 < (b0 < max_t ? b0 : max_t)), o1 = mine & (n1 < (b1 < max_t ? b1 : max_t));
+                const unsigned long long m_open = __ballot(mine), m_new0 = __ballot(o0 & (n0 == 0)), m_new1 = __ballot(o1 & (n1 == 0));
+                const unsigned long long m_o0 = __ballot(o0), m_o1 = __ballot(o1), m_form = __ballot(mine & !o0 & !o1 & (pd == 0));
+                if ((m_new0 | m_new1) != 0ull) {  // a search nobody has begun
+                    const int i = __builtin_ctzll(m_new0 | m_new1);
+                    act = 1; sel = 2 * i + (((m_new0 >> i) & 1ull) != 0ull ? 0 : 1);
+                } else {
+                    if (m_form != 0ull) {  // both searches of an entry closed, nobody at work on them: one wavefront forms the reset
+                        const int i = __builtin_ctzll(m_form);
+                        int won = 0;
+                        if (lane == 0) {
+                            int expect = 0;
+                            won = __hip_atomic_compare_exchange_strong(&coop_state[i], &expect, 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+                        }
+                        if (__builtin_amdgcn_readfirstlane(won) != 0) { act = 2; sel = i; }
+                    }
+#ifndef GPR_COOP_NO_HELP
+                    if (act == 0 && (m_o0 | m_o1) != 0ull) {  // join the oldest search still open
+                        const int i = __builtin_ctzll(m_o0 | m_o1);
+                        act = 1; sel = 2 * i + (((m_o0 >> i) & 1ull) != 0ull ? 0 : 1);
+                        GPR_WT(cn_help += 1;)
+                    }
+#endif
+                }
+                if (act == 1 && lane == 0) __hip_atomic_fetch_add(&coop_pend[sel >> 1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);  // at work from here on
+                if (act == 0 && m_open == 0ull && all_through) act = 3;
+            }
+            act = __builtin_amdgcn_readfirstlane(act);
+            GPR_WT(const long long ct1 = __builtin_amdgcn_s_memtime(); ct_scan += ct1 - ct0;)
+            if (act == 3) break;
+            if (act == 0) { GPR_WT(cn_poll += 1;) __builtin_amdgcn_s_sleep(8); continue; }
+            sel = __builtin_amdgcn_readfirstlane(sel);
+            const int ei = act == 1 ? sel >> 1 : sel;
+            int entry;
+            do { entry = __hip_atomic_load(&reset_list[ei], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (entry < 0);
+            const int64_t renv = env_block_base + (entry >> 1);
+            R2<RT> rp{(RT)0, (RT)0}, rg{(RT)0, (RT)0};
+            if (act == 1) {
+                bool rwc, rmc;
+                group_reset<ST, RT, LPE, NOISE, FULL, SHAPE, false, 1>(P, T, P.env_id_offset + renv, mv, mvc, mv < M, true, c, c1, GROUPS, rp, rg, rwc, rmc, sel & 1, &coop_next[sel], &coop_best[sel]);
+                if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&coop_pend[ei], -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                GPR_WT(ct_sess += __builtin_amdgcn_s_memtime() - ct1; cn_sess += 1;)
+            } else {
+                int ts = ld(&coop_best[2 * ei]), tg = ld(&coop_best[2 * ei + 1]);  // (final: see above)
+                ts = ts < max_t ? ts : max_t - 1; tg = tg < max_t ? tg : max_t - 1;  // trials exhausted: the last candidate stands
+                GPR_WT(wt_served += 1;)
+                serve(1, GROUPS, true, renv, (entry & 1) != 0, rp, rg, true, ts, tg);
+                GPR_WT(ct_form += __builtin_amdgcn_s_memtime() - ct1;)
+            }
+        }
+        GPR_WT(wt_clamp = (int)ct_scan; wt_near = (int)ct_sess; wt_rows = (int)ct_form; wt_direct = cn_poll; wt_due = cn_sess; wt_exact = cn_help;)  // (timing builds: the cooperative search's own clocks in place of the loop's counts)
     } else {
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&waves_through, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {

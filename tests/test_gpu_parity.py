@@ -332,6 +332,11 @@ FREE_RUNNING_F64 = [
     (np.ones((8, 8)), 8, {'std_noise': np.array([1e-4, 2e-4, 0.0])}),                                    # wide noise bands, 8 lanes per env
     (np.ones((10, 10)), 16, {'E': 2048, 'steps': 60}),   # BASELINE config 5's shape: parallel reset trials (~45 rejections per reset), 16 lanes per env
     (np.ones((8, 8)), 8, {'E': 4096, 'steps': 60}),      # BASELINE config 4's shape
+    # the shared searches of the 16-lane kernels (a block's wavefronts take rounds of four trials from one counter per search): a trial bound
+    # that is not a multiple of a round and that most searches run into (the last candidate stands: PL:369 with a bound), and a padded
+    # group (12 movers in 16 lanes) on a layout so tight that a search takes hundreds of rounds
+    (np.ones((10, 10)), 16, {'E': 1024, 'steps': 40, 'max_reset_trials': 6}),
+    (np.ones((7, 7)), 12, {'E': 1024, 'steps': 40}),
 ]
 
 

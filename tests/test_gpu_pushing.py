@@ -52,13 +52,20 @@ def test_free_space_actuation_matches_reference_closed_form(gpr, precision, tol)
 
 @pytest.mark.parametrize('precision', ['f64', 'f32_f64acc', 'f32'])
 @pytest.mark.parametrize('kw', [{}, {'learn_jerk': True}, {'autoreset_mode': 'next_step', 'std_noise': 0.0}, {'num_movers': 2},
-                                {'num_movers': 2, 'learn_jerk': True, 'E': 4096}])
-def test_step_reset_vs_oracle(gpr, oracle, precision, kw):
+                                {'num_movers': 2, 'learn_jerk': True, 'E': 4096}, {'num_movers': 2, 'pair_lanes': '0'}])
+def test_step_reset_vs_oracle(gpr, oracle, precision, kw, monkeypatch):
     kw = dict(kw)
     E = kw.pop('E', 333)
     NM = kw.get('num_movers', 1)
     if E > 1000 and precision != 'f64':
         pytest.skip('the 4 096-env run of BASELINE config 3 is compared in the pinning precision only')
+    # two movers in float: a batch this small runs one lane per (mover, object) pair (k_push<..., PAIR>); the form with both pairs in every
+    # lane -- what batches beyond two wavefronts per SIMD run -- is held to the same bounds by switching pair lanes off
+    pair = kw.pop('pair_lanes', None)
+    if pair is not None:
+        if precision != 'f32':
+            pytest.skip('pair lanes exist in the float build only')
+        monkeypatch.setenv('GPR_PUSH_PAIR', pair)
     autoreset = kw.pop('autoreset_mode', 'same_step')
     genv = gpr.VecBenchmarkPushingEnv(num_envs=E, precision=precision, autoreset_mode=autoreset, env_id_offset=77, **kw)
     okw = dict(kw); okw.setdefault('std_noise', 1e-5)
@@ -118,7 +125,7 @@ def test_step_reset_vs_oracle(gpr, oracle, precision, kw):
         n_contact += int((np.abs(oenv.object[:, 3:5]).max(axis=1) > 0).sum()); n_term += int(o['terminated'].sum())
     assert n_contact > 100 and n_term > 0, (n_contact, n_term)
     assert mism <= (0 if precision == 'f64' else 5)
-    record_metric(f'pushing_step_reset_vs_oracle[{precision}-NM{NM}-E{E}-{"jerk" if kw.get("learn_jerk") else "acc"}-{autoreset}]',
+    record_metric(f'pushing_step_reset_vs_oracle[{precision}-NM{NM}-E{E}-{"jerk" if kw.get("learn_jerk") else "acc"}-{autoreset}{"-one-lane" if pair == "0" else ""}]',
                   flag_mismatches=mism, env_steps=70 * E, worst_object_velocity_event=worst, tol=tol)
     genv.close()
 
