@@ -772,11 +772,19 @@ template <typename RT, int LPE, int D> struct PairSweep {
             typedef RT V2 __attribute__((ext_vector_type(2)));
             RT dx0, dy0, dx1, dy1;
             rot_diff4<LPE, D>(x, y, dx0, dy0, dx1, dy1);
-            const V2 dx{dx0, dx1}, dy{dy0, dy1};
-            const V2 m = __builtin_elementwise_fma(dx, dx, dy * dy);
-            const RT mm = __builtin_fminf(m.x, m.y);
-            if constexpr (D + 1 < LPE / 2) return __builtin_fminf(PairSweep<RT, LPE, D + 2>::run(x, y), mm);
-            else return mm;
+            if constexpr (LPE >= 8) {
+                // wide groups: plain multiplies and fma's (gfx950 wants a wait state around every dependent packed instruction -- the
+                // assembler pads them with s_nop 0, and a padded packed pair is no cheaper than two plain instructions), three-way minima
+                const RT m0 = __builtin_fmaf(dx0, dx0, dy0 * dy0), m1 = __builtin_fmaf(dx1, dx1, dy1 * dy1);
+                if constexpr (D + 1 < LPE / 2) return __builtin_fminf(__builtin_fminf(PairSweep<RT, LPE, D + 2>::run(x, y), m0), m1);  // (v_min3_f32)
+                else return __builtin_fminf(m0, m1);
+            } else {
+                const V2 dx{dx0, dx1}, dy{dy0, dy1};
+                const V2 m = __builtin_elementwise_fma(dx, dx, dy * dy);
+                const RT mm = __builtin_fminf(m.x, m.y);
+                if constexpr (D + 1 < LPE / 2) return __builtin_fminf(PairSweep<RT, LPE, D + 2>::run(x, y), mm);
+                else return mm;
+            }
         }
     }
 };

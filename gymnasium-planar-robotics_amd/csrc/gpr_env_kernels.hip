@@ -117,8 +117,8 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
         }
     };
-    // the verdict on this lane group's candidate set member cn of `pass` (wave-cooperative: every lane calls it)
-    auto rejected = [&](int pass, R2<RT> cn) {
+    // is this lane's member cn of its group's candidate set of `pass` in conflict with a wall or another member (wave-cooperative: every lane calls it)
+    auto conflict = [&](int pass, R2<RT> cn) {
         bool w, hit;
         if constexpr (SHAPE == 0) {
             w = live & !pos_valid_circle<RT, FULL>(T, P, cn.x, cn.y, cw_safe);                    // PL:379 / PL:403-404
@@ -136,8 +136,9 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             }
             else hit = live & dist_lt<RT>(pair_min_dist<RT, LPE>(cn.x, cn.y), C.min_goal_dist);
         }
-        return group_any<LPE>(w | hit);
+        return w | hit;
     };
+    auto rejected = [&](int pass, R2<RT> cn) { return group_any<LPE>(conflict(pass, cn)); };  // the verdict on the lane group's candidate set
     if constexpr (MODE == 1) {
         // one wavefront's stay with a shared search (all S groups on the same env): rounds of S trials claimed from *coop_next until no
         // unclaimed trial lies below the best valid one posted in *coop_best; the next claim is made BEFORE the round in hand is evaluated
@@ -158,11 +159,15 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             if (!(b < (lim < max_t ? lim : max_t))) break;  // nothing unclaimed below the best valid trial (or the bound): the search is closed
             claim();
             for (int r = 0; r < RPC && !found; ++r) {
-                const int trial = b + r * S + slot;
-                const bool bad = rejected(coop_pass, candidate(key, trial));
-                const unsigned long long seg = (__ballot(need & !bad & (trial < max_t)) >> lead_lane) & set_mask;
-                if (seg != 0ull) {
-                    if (__lane_id() == 0u) __hip_atomic_fetch_min(coop_best, b + r * S + (int)(__builtin_ctzll(seg) / LPE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // one trial per lane group (S == 64 / LPE == 4 groups of 16 lanes): the first group without a lane in conflict, straight
+                // from the ballot in scalar registers
+                static_assert(LPE == 16, "the shared search is the 16-lane kernels'");
+                const int t0 = b + r * S;
+                const unsigned long long bm = __ballot(conflict(coop_pass, candidate(key, t0 + slot)));
+                const uint32_t lo = (uint32_t)bm, hi = (uint32_t)(bm >> 32);
+                const int gv = (lo & 0xFFFFu) == 0u ? 0 : (lo >> 16) == 0u ? 1 : (hi & 0xFFFFu) == 0u ? 2 : (hi >> 16) == 0u ? 3 : 4;
+                if ((gv < 4) & (t0 + gv < max_t)) {  // (trials grow with the group: if the first valid one lies beyond the bound, all do)
+                    if (__lane_id() == 0u) __hip_atomic_fetch_min(coop_best, t0 + gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     found = true;  // (whatever this wavefront has claimed beyond lies above the trial just posted)
                 }
             }
