@@ -1568,8 +1568,23 @@ __global__ void __launch_bounds__(BLOCK) k_reset(const KParams P) {
 // -----------------------------------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------------------------------
+// GPR_ENV_PART: the float / float kernels are built in TWO translation units (Makefile). Part 0: the circle shape in groups of up to 8
+// lanes, with the compiler's SLP vectoriser on (the headline kernel loses 1.5 % without the packed instructions it forms). Part 1: the
+// 'box' shape and the 16-lane groups, compiled -fno-slp-vectorize -- the packed instructions the vectoriser forms out of the rectangle
+// tests and the reset searches need register moves to pair their operands and a wait state each on gfx950: the box kernel drops from 205
+// to 160 registers (three wavefronts per SIMD instead of two; 83.7 -> 78.6 us as one launch, 52.7 -> 51.4 with four sub-batches), the
+// 16-mover kernel gains 3 %. Undefined: one unit with everything (the parity precisions).
+#ifndef GPR_ENV_PART
+#define GPR_ENV_PART -1
+#endif
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
 static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) {
+    constexpr bool WIDE = LPE == 16 || SHAPE != 0;
+    if constexpr (GPR_ENV_PART == 0 && WIDE) {
+        return launch_env_kernel_wide<ST, RT>(is_reset, LPE, P, s);  // (the kernel is not instantiated in this unit)
+    } else if constexpr (GPR_ENV_PART == 1 && !WIDE) {
+        return hipErrorInvalidValue;                                  // (nor this one in the other)
+    } else {
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
     const unsigned lds = (FULL && SHAPE == 0 && !Math<RT>::literal) ? 0u : P.table_bytes;
@@ -1592,6 +1607,7 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
         hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
     }
     return hipGetLastError();
+    }
 }
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE> static hipError_t launch_one(bool is_reset, const KParams &P, hipStream_t s) {
     if (P.c_shape != 0) {  // 'box' collision shape; grids without holes have a fast wall test here too (see gpr_create)
@@ -1620,7 +1636,7 @@ template <typename ST, typename RT, int LPE> static hipError_t launch_flags(bool
     }
     return noise ? launch_one<ST, RT, LPE, false, true>(is_reset, P, s) : launch_one<ST, RT, LPE, false, false>(is_reset, P, s);
 }
-template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s) {
+template <typename ST, typename RT> static hipError_t launch_by_lanes(bool is_reset, int lpe, const KParams &P, hipStream_t s) {
     switch (lpe) {
         case 1: return launch_flags<ST, RT, 1>(is_reset, P, s);
         case 2: return launch_flags<ST, RT, 2>(is_reset, P, s);
@@ -1634,11 +1650,21 @@ template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, 
 #ifndef GPR_ENV_TYPES
 #error "define GPR_ENV_TYPES as ST,RT (one translation unit per precision)"
 #endif
+#if GPR_ENV_PART == 1
+template <typename ST, typename RT> hipError_t launch_env_kernel_wide(bool is_reset, int lpe, const KParams &P, hipStream_t s) {
+    return launch_by_lanes<ST, RT>(is_reset, lpe, P, s);
+}
+template hipError_t launch_env_kernel_wide<GPR_ENV_TYPES>(bool, int, const KParams &, hipStream_t);
+#else
+template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s) {
+    return launch_by_lanes<ST, RT>(is_reset, lpe, P, s);
+}
 // this translation unit's instance of the normal-draw tables (gpr_device.h)
 template <typename ST, typename RT> hipError_t set_normal_table_env(const double *tab) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_normal_tab), &tab, sizeof(tab));
 }
 template hipError_t set_normal_table_env<GPR_ENV_TYPES>(const double *);
 template hipError_t launch_env_kernel<GPR_ENV_TYPES>(bool, int, const KParams &, hipStream_t);
+#endif
 
 }  // namespace gpr

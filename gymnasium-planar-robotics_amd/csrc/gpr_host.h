@@ -19,6 +19,8 @@ inline hipError_t raise_dynamic_lds(const void *fn, int bytes, bool (&flags)[GPR
 
 // fused env kernels, one instantiation per (storage, compute) precision, each in its own translation unit
 template <typename ST, typename RT> hipError_t launch_env_kernel(bool is_reset, int lpe, const KParams &P, hipStream_t s);
+// (the float kernels of the 'box' shape and of the 16-lane groups live in a translation unit of their own, see GPR_ENV_PART in gpr_env_kernels.hip)
+template <typename ST, typename RT> hipError_t launch_env_kernel_wide(bool is_reset, int lpe, const KParams &P, hipStream_t s);
 
 // P carries the step outputs (obs / ag / dg / reward / terminated / truncated / final_*) the views are built from
 template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, void *agent_obs, void *agent_reward, hipStream_t s);
