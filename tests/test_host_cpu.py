@@ -420,3 +420,18 @@ def test_without_gymnasium_nothing_is_registered():
     assert gpr.spaces.HAVE_GYMNASIUM is False and gpr.registered_ids == []
     e = gpr.VecBenchmarkPlanningEnv(np.ones((3, 3)), 1, num_envs=2, _host_only=True)
     assert e.metadata['autoreset_mode'] == 'same_step' and e.single_action_space.shape == (2,)
+
+
+def test_shared_reset_search_protocol_model(tmp_path):
+    """the wave-cooperative protocol of the 16-lane kernels' shared reset searches (gpr_env_kernels.hip: counters in LDS, no barrier, no
+    wavefront ever waits for another one's result) as a host model, one thread per wavefront, thousands of randomly scheduled runs: every
+    queued entry is formed exactly once and from the FIRST valid trial of both of its searches, every wavefront leaves. The mutant that
+    forms a reset without looking at who is still at work must be caught -- the model can see the race the counter exists for."""
+    src = os.path.join(ROOT, 'tests', 'model', 'coop_search_model.cpp')
+    good, bad = str(tmp_path / 'coop_model'), str(tmp_path / 'coop_model_mutant')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-pthread', src, '-o', good], check=True)
+    subprocess.run(['g++', '-O2', '-std=c++17', '-pthread', '-DMODEL_BREAK_AT_WORK', src, '-o', bad], check=True)
+    r = subprocess.run([good, '4000', '11'], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and 'ok: 4000 runs' in r.stdout, r.stdout[-500:]
+    r = subprocess.run([bad, '20000', '11'], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 1 and 'expected' in r.stdout, 'the mutant went through: the model no longer exercises the race'
