@@ -340,6 +340,36 @@ def timed_rollout_launch(args, rank, local_rank, world, envs, n_steps=T_ROLLOUT)
             'us_per_step': us, 'hbm_frac': algorithmic_bytes_per_env_step(args.movers, args.precision) * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
+def timed_pushing(args, local_rank, envs, movers):
+    """BASELINE config 3: the pushing env (one launch per step; the reference's env has 1 mover, the 2-mover variant is engine-defined)"""
+    import torch
+
+    import gymnasium_planar_robotics_amd as gpr
+
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    env = gpr.VecBenchmarkPushingEnv(num_envs=envs, num_movers=movers, device=device)
+    env.reset(seed=0)
+    gen = torch.Generator(device=device).manual_seed(1234)
+    env.elapsed_steps.copy_(torch.randint(0, T_ROLLOUT, (envs,), device=device, generator=gen, dtype=torch.int32))
+    acts = [(torch.rand(envs, 2 * movers, device=device, generator=gen) * 20 - 10) for _ in range(8)]
+    n = 100
+    with torch.cuda.device(device):
+        for i in range(30):
+            env.step(acts[i % 8])
+        best = float('inf')
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n):
+                env.step(acts[i % 8])
+            e1.record()
+            torch.cuda.synchronize(device)
+            best = min(best, e0.elapsed_time(e1) / n * 1e3)
+    env.close()
+    return {'envs': envs, 'movers': movers, 'step_us': best, 'env_steps_per_s': envs / best * 1e6}
+
+
 def cpu_baseline(args):
     """The oracle (plain-C port of the reference semantics, fp64) on this box's host cores: a bounded sample of the same workload."""
     import numpy as np
@@ -475,6 +505,21 @@ def main():
                                  'hbm_frac': algorithmic_bytes_per_env_step(M, args.precision) * n / (r['step_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
             cfg['other_batch_sizes'] = sizes
             cfg['rollout_launch'] = {str(n): timed_rollout_launch(args, rank, local_rank, world, n) for n in (8192, E)}
+            if (M, args.tiles, args.precision) == (4, 6, 'f32'):
+                # BASELINE.json's other configurations at the size ONE GPU of its node gets, and whole (parity-test cases, not the headline;
+                # config 2 = other_batch_sizes['4096'])
+                shapes = {}
+                for name, kw in (('config4_shard: 8 movers x 8192 envs', dict(envs=8192, movers=8, tiles=8)),
+                                 ('config4: 8 movers x 65536 envs', dict(envs=65536, movers=8, tiles=8)),
+                                 ('config5_shard: 16 movers x 4096 envs', dict(envs=4096, movers=16, tiles=10)),
+                                 ('config5: 16 movers x 32768 envs', dict(envs=32768, movers=16, tiles=10))):
+                    r = timed(args, rank, local_rank, world, steps=100, warmup=40, sub=S, **kw)
+                    shapes[name] = {'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us'], 'sub_batches': r['sub_batches'],
+                                    'hbm_frac': algorithmic_bytes_per_env_step(kw['movers'], 'f32') * kw['envs'] / (r['step_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                for nm in (1, 2):
+                    r = timed_pushing(args, local_rank, 4096, nm)
+                    shapes[f'config3: pushing env, {nm} mover(s) x 4096 envs, one launch per step'] = {'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us']}
+                cfg['baseline_configs'] = shapes
             if args.precision == 'f32':
                 # the reference's own arithmetic (float64): its own roofline block, kernel name and bytes
                 ref = {}
