@@ -9,9 +9,11 @@ E, steps = 4096, 200
 for name, layout, M, kw in (('6x6 circles', np.ones((6, 6)), 4, {}),
                             ('holes', HOLES, 3, {'collision_params': {'shape': 'circle', 'size': 0.1, 'offset': 0.005, 'offset_wall': 0.002}}),
                             ('box', np.ones((5, 5)), 3, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775]), 'offset': 0.002}}),
-                            ('jerk', np.ones((6, 6)), 4, {'learn_jerk': True}), ('8 movers', np.ones((8, 8)), 8, {})):
+                            ('jerk', np.ones((6, 6)), 4, {'learn_jerk': True}), ('8 movers', np.ones((8, 8)), 8, {}),
+                            ('16 movers (shared reset searches)', np.ones((10, 10)), 16, {}), ('12 movers on 8x8 (padded groups, long searches)', np.ones((8, 8)), 12, {})):
+    if len(sys.argv) > 1 and sys.argv[1] not in name: continue
     genv = gpr.VecBenchmarkPlanningEnv(layout, M, num_envs=E, precision='f64', **kw)
-    oenv = oracle.OraclePlanningEnv(layout, M, E, autoreset='same_step', max_episode_steps=50, storage_f32=False, std_noise=1e-5, **kw)
+    oenv = oracle.OraclePlanningEnv(layout, M, E, autoreset='same_step', max_episode_steps=50, storage_f32=False, std_noise=1e-5, num_threads=16, **kw)
     genv.reset(seed=11); oenv.reset(seed=11)
     rng = np.random.default_rng(5); lim = genv.j_max if genv.learn_jerk else genv.a_max
     mism = 0; worst = 0.0; done = 0
