@@ -16,3 +16,12 @@ stat('cycles + own stores', f[:, 0]); stat('queue service / wait', f[:, 1]); sta
 if 'nocoop' not in os.environ.get('GPR_LIB_PATH', ''):
     stat('  scanning', f[:, 2]); stat('  in searches', f[:, 3]); stat('  forming resets', f[:, 5]); stat('  polls with nothing to do', f[:, 6]); stat('  searches joined', f[:, 7]); stat('  of which to help', f[:, 11])
 t0 = f[:, 12]; t1 = f[:, 13]; print('  kernel span (first start to last end):', ((t1 - t0.min()) % 2**32).max())
+# per block (4 consecutive wavefronts): is the queue service balanced inside the block, and how do the blocks compare?
+blk = (f[:, 0] + f[:, 1]).reshape(-1, 4)
+srv = f[:, 1].reshape(-1, 4)
+print('  per block: total clocks of its slowest wavefront'); stat('    slowest wavefront of the block', blk.max(axis=1)); stat('    mean wavefront of the block', blk.mean(axis=1))
+stat('    spread inside the block (max - min of queue service)', srv.max(axis=1) - srv.min(axis=1))
+formed = f[:, 4].reshape(-1, 4).sum(axis=1); stat('    resets formed per block', formed)
+c = np.corrcoef(formed, blk.max(axis=1))[0, 1]; print(f'    correlation(resets of the block, its slowest wavefront) = {c:.2f}')
+if 'nocoop' not in os.environ.get('GPR_LIB_PATH', ''):
+    ss = f[:, 3].reshape(-1, 4).sum(axis=1); stat('    search clocks per block (sum over its wavefronts)', ss); stat('    search clocks per reset', ss / np.maximum(formed, 1))
