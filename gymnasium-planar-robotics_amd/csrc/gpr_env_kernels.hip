@@ -145,7 +145,10 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
         // (its LDS round trip hides behind the round; a claim that turns out to lie above the best trial is simply dropped)
         const uint32_t key = coop_pass == 0 ? ks : kg;
         const int max_t = P.max_reset_trials;
-        constexpr int RPC = 2;  // rounds per claim
+#ifndef GPR_COOP_RPC
+#define GPR_COOP_RPC 2
+#endif
+        constexpr int RPC = GPR_COOP_RPC;  // rounds per claim (same device, us per step at 4 096 / 32 768 envs x 16 movers -- 1: 58.1 / 119.8, 2: 52.9 / 114.9, 4: 53.6 / 115.4)
         int cl = 0, seen = 0;   // (lane 0) the claim made ahead and the best trial seen with it; judged when its turn comes
         auto claim = [&]() {
             if (__lane_id() == 0u) {
