@@ -18,6 +18,7 @@
 
 #include "../../include/gpr.h"
 #include "gpr_host.h"
+#include "gpr_launch_worker.h"
 
 using namespace gpr;
 
@@ -334,75 +335,41 @@ int push_launch(gpr_env *env, bool is_reset, const KParams &P, hipStream_t s, co
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LAUNCH WORKERS (gpr_step_many). A kernel launch costs the host ~3.5 us (scratch/ubench/graphlaunch.hip: 3.46 us per launch issued from
-// one thread, 19.6 us for four on four streams in a sustained loop) -- as long as a 16 384-env sub-batch takes the GPU. Launches on
-// DIFFERENT streams from DIFFERENT host threads do run in parallel (4.3 us for the same four), so gpr_step_many hands launch i > 0 to
-// worker thread i and issues launch 0 itself. A worker spins on its mailbox while steps keep coming (a step is due every ~13 us) and
-// goes to sleep on a condition variable after ~200 us without work, so an idle process burns nothing. Workers are created on first
-// use, never destroyed (a process that is exiting must not join threads that may be inside the HIP runtime).
-// GPR_LAUNCH_THREADS=0 keeps every launch on the calling thread.
+// LAUNCH WORKERS (gpr_step_many): gpr_launch_worker.h holds the worker itself (plain C++, also built under -fsanitize=thread against a
+// stub launch by tests/model/launch_worker_stress.cpp). Workers are created on first use and never joined (a process that is exiting
+// must not join threads that may be inside the HIP runtime); a worker that does not answer within GPR_LAUNCH_TIMEOUT_MS (default
+// 30 000) is abandoned and replaced. GPR_LAUNCH_THREADS=0 keeps every launch on the calling thread.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-struct LaunchJob {
-    gpr_env *env = nullptr;
-    const void *action = nullptr;
-    const gpr_step_out *out = nullptr;
-    void *stream = nullptr;
-    int rc = GPR_OK;
-};
-struct LaunchWorker {
-    std::atomic<int> state{0};  // 0 idle, 1 job posted, 2 job done
-    LaunchJob job;
-    std::mutex m;
-    std::condition_variable cv;
-    std::atomic<bool> asleep{false};
-    int device = -1;
-    void run() {
-        for (;;) {
-            int spins = 0;
-            while (state.load(std::memory_order_acquire) != 1) {
-                if (++spins < 20000) {  // ~200 us of polling
-                    __builtin_ia32_pause();
-                } else {
-                    std::unique_lock<std::mutex> lk(m);
-                    asleep.store(true, std::memory_order_release);
-                    cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1; });
-                    asleep.store(false, std::memory_order_release);
-                    spins = 0;
-                }
-            }
-            if (job.env->device != device) { device = job.env->device; (void)hipSetDevice(device); }  // (the current device is per thread)
-            job.rc = gpr_step(job.env, job.action, job.out, job.stream);
-            state.store(2, std::memory_order_release);
-        }
+int run_launch_job(const LaunchJob &j) {
+    thread_local int device = -1;  // (the current device is per thread)
+    gpr_env *env = static_cast<gpr_env *>(j.env);
+    if (env->device != device) {
+        const hipError_t he = hipSetDevice(env->device);
+        if (he != hipSuccess) return fail_hip(env, he, "gpr_step_many: hipSetDevice on a launch worker");
+        device = env->device;
     }
-    void post(const LaunchJob &j) {
-        job = j;
-        state.store(1, std::memory_order_release);
-        if (asleep.load(std::memory_order_acquire)) {
-            std::lock_guard<std::mutex> lk(m);
-            cv.notify_one();
-        }
-    }
-    int wait() {
-        while (state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
-        const int rc = job.rc;
-        state.store(0, std::memory_order_relaxed);
-        return rc;
-    }
-};
+    return gpr_step(env, j.action, static_cast<const gpr_step_out *>(j.out), j.stream);
+}
 constexpr int MAX_LAUNCH_WORKERS = 7;
-LaunchWorker *launch_worker(int i) {  // worker i, created on first use (called by one thread at a time per process: gpr_step_many's lock)
-    static LaunchWorker *pool[MAX_LAUNCH_WORKERS] = {};
-    if (!pool[i]) {
-        pool[i] = new LaunchWorker();
-        std::thread([w = pool[i]] { w->run(); }).detach();
+constexpr int LAUNCH_SPIN_LIMIT = 20000;  // ~200 us of polling before a worker goes to sleep
+LaunchWorker *g_launch_pool[MAX_LAUNCH_WORKERS] = {};
+LaunchWorker *launch_worker(int i) {  // worker i, created on first use (called under gpr_step_many's pool lock)
+    LaunchWorker *&w = g_launch_pool[i];
+    if (w && w->lost()) w = nullptr;  // (the abandoned worker and its thread are leaked on purpose: it may still be inside the runtime)
+    if (!w) {
+        w = new LaunchWorker(run_launch_job, LAUNCH_SPIN_LIMIT);
+        std::thread([p = w] { p->run(); }).detach();
     }
-    return pool[i];
+    return w;
 }
 bool launch_threads_enabled() {
     static const bool on = [] { const char *e = std::getenv("GPR_LAUNCH_THREADS"); return !(e && e[0] == '0'); }();
     return on;
+}
+long launch_timeout_ms() {
+    static const long ms = [] { const char *e = std::getenv("GPR_LAUNCH_TIMEOUT_MS"); const long v = e ? std::atol(e) : 0; return v > 0 ? v : 30000L; }();
+    return ms;
 }
 }  // namespace
 
@@ -662,6 +629,8 @@ int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_de
         if (!actions_dev[i]) return fail(envs[i], GPR_E_INVALID, "gpr_step_many: action is NULL");
         const int rc = check_out(envs[i], outs[i]);
         if (rc != GPR_OK) return rc;
+        for (int32_t j = 0; j < i; ++j)  // (two launches of one handle would run on two threads and race on its call counter)
+            if (envs[j] == envs[i]) return fail(envs[i], GPR_E_INVALID, "gpr_step_many: the same handle appears twice");
     }
     if (n == 1 || !launch_threads_enabled()) {
         for (int32_t i = 0; i < n; ++i) {
@@ -670,7 +639,7 @@ int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_de
         }
         return GPR_OK;
     }
-    // launches 1 .. n-1 go to the launch workers (see LaunchWorker), launch 0 is issued here; handles beyond the pool stay on this thread
+    // launches 1 .. n-1 go to the launch workers (gpr_launch_worker.h), launch 0 is issued here; handles beyond the pool stay on this thread
     static std::mutex pool_lock;  // (one gpr_step_many at a time per process uses the workers)
     std::lock_guard<std::mutex> lk(pool_lock);
     for (int32_t i = 0; i < n; ++i) {
@@ -678,14 +647,18 @@ int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_de
         if (rc != GPR_OK) return rc;
     }
     const int32_t n_workers = std::min<int32_t>(n - 1, MAX_LAUNCH_WORKERS);
-    for (int32_t w = 0; w < n_workers; ++w) launch_worker(w)->post(LaunchJob{envs[1 + w], actions_dev[1 + w], outs[1 + w], hip_streams[1 + w], GPR_OK});
+    for (int32_t w = 0; w < n_workers; ++w)
+        launch_worker(w)->post(LaunchJob{envs[1 + w], actions_dev[1 + w], outs[1 + w], hip_streams[1 + w], GPR_OK});
     int rc = gpr_step(envs[0], actions_dev[0], outs[0], hip_streams[0]);
     for (int32_t i = 1 + n_workers; i < n; ++i) {
         const int r = gpr_step(envs[i], actions_dev[i], outs[i], hip_streams[i]);
         if (rc == GPR_OK) rc = r;
     }
     for (int32_t w = 0; w < n_workers; ++w) {
-        const int r = launch_worker(w)->wait();
+        int r = launch_worker(w)->wait(launch_timeout_ms());
+        if (r == LaunchWorker::WAIT_TIMED_OUT)  // (the worker is abandoned and replaced at the next call; its launch may or may not have been issued)
+            r = fail(envs[1 + w], GPR_E_HIP, "gpr_step_many: launch worker " + std::to_string(w) + " did not return within " +
+                                                 std::to_string(launch_timeout_ms()) + " ms (GPR_LAUNCH_TIMEOUT_MS); GPR_LAUNCH_THREADS=0 issues every launch on the calling thread");
         if (rc == GPR_OK) rc = r;
     }
     return rc;
@@ -698,6 +671,8 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
     if (env->cfg.autoreset_mode == GPR_AUTORESET_DISABLED && n_steps > 1)
         return fail(env, GPR_E_INVALID, "gpr_step_n: several steps per launch need an autoreset mode (a finished env must go on)");
     int rc = check_out(env, out);
+    if (rc != GPR_OK) return rc;
+    rc = check_device(env, "gpr_step_n");  // before anything is allocated for the handle: the slots below live on the current device
     if (rc != GPR_OK) return rc;
     if (out->desired_goal_dev == env->state.goal_dev && n_steps > 1)
         return fail(env, GPR_E_INVALID, "gpr_step_n: desired_goal must not alias the goal state (every step keeps its own)");
@@ -748,11 +723,10 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
     P.n_steps = n_steps;
     P.step_params = sl.dev;
     rc = launch_env(env, false, P, as_stream(hip_stream));
-    if (rc == GPR_OK) {
-        env->tick += (uint64_t)n_steps;
-        if (hipEventRecord(sl.done, as_stream(hip_stream)) == hipSuccess) sl.busy = true;
-        else (void)hipStreamSynchronize(as_stream(hip_stream));  // (cannot track the launch: wait for it here)
-    }
+    if (rc == GPR_OK) env->tick += (uint64_t)n_steps;
+    // the upload is enqueued whether or not the launch went out, and it reads sl.host: track it (or wait for it here)
+    if (hipEventRecord(sl.done, as_stream(hip_stream)) == hipSuccess) sl.busy = true;
+    else (void)hipStreamSynchronize(as_stream(hip_stream));
     return rc;
 }
 

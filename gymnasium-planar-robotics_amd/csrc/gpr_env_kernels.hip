@@ -1594,7 +1594,7 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     // the tile tables of a large layout (64 x 64 cells in f64: 47 KB) plus the kernels' static LDS exceed the 64 KB a launch
     // gets by default: raise the kernel's limit once (gfx950 has 160 KB per CU; gpr_create bounds the table size)
     if (lds > 32u * 1024u) {
-        static bool raised[3][GPR_MAX_DEVICES];  // per (kernel, device): the attribute belongs to the device's code object
+        static LdsFlag raised[3][GPR_MAX_DEVICES];  // per (kernel, device): the attribute belongs to the device's code object
         const int which = is_reset ? 0 : (P.n_steps > 1 ? 2 : 1);
         const void *fn = is_reset ? reinterpret_cast<const void *>(&k_reset<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)
                                   : (P.n_steps > 1 ? reinterpret_cast<const void *>(&k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>)

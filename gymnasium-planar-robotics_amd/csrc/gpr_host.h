@@ -1,19 +1,23 @@
 // gpr_host.h -- launcher declarations shared by the translation units of libgpr_hip.so
 #pragma once
+#include <atomic>
+
 #include "gpr_device.h"
 
 namespace gpr {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE attribute of a kernel: remember per (kernel, device) that it was
-// raised, and only once the call succeeded. `flags` is the kernel's own static array (zero-initialised).
+// raised, and only once the call succeeded. `flags` is the kernel's own static array (zero-initialised). The launch workers of
+// gpr_step_many reach this from several threads for the same kernel: the flags are atomic, and setting the attribute twice is harmless.
 constexpr int GPR_MAX_DEVICES = 64;
-inline hipError_t raise_dynamic_lds(const void *fn, int bytes, bool (&flags)[GPR_MAX_DEVICES]) {
+using LdsFlag = std::atomic<bool>;
+inline hipError_t raise_dynamic_lds(const void *fn, int bytes, LdsFlag (&flags)[GPR_MAX_DEVICES]) {
     int dev = 0;
     hipError_t he = hipGetDevice(&dev);
     if (he != hipSuccess) return he;
-    if (dev >= 0 && dev < GPR_MAX_DEVICES && flags[dev]) return hipSuccess;
+    if (dev >= 0 && dev < GPR_MAX_DEVICES && flags[dev].load(std::memory_order_acquire)) return hipSuccess;
     he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (he == hipSuccess && dev >= 0 && dev < GPR_MAX_DEVICES) flags[dev] = true;
+    if (he == hipSuccess && dev >= 0 && dev < GPR_MAX_DEVICES) flags[dev].store(true, std::memory_order_release);
     return he;
 }
 

@@ -203,7 +203,7 @@ template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, 
     const unsigned grid = (unsigned)((P.E * lpe + AV_BLOCK - 1) / AV_BLOCK);
     const unsigned lds = (unsigned)((AV_BLOCK / 64) * (64 / lpe) * P.M * (4 * P.M + 2) * sizeof(ST));
     hipError_t err = hipSuccess;
-    static bool raised[17][GPR_MAX_DEVICES];  // per (kernel = lanes per env, device); one array per ST (this function is a template)
+    static LdsFlag raised[17][GPR_MAX_DEVICES];  // per (kernel = lanes per env, device); one array per ST (this function is a template)
     auto a = [&](auto K) {
         if (lds > 48u * 1024u) err = raise_dynamic_lds(reinterpret_cast<const void *>(K), 80 * 1024, raised[lpe & 16 ? 16 : lpe]);
         if (err == hipSuccess)

@@ -336,17 +336,20 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
         are (batch,) tensors / arrays (what ``step()`` returns). -> (mover_collision, wall_collision, scalar)"""
         if isinstance(info, (np.ndarray, list, tuple)):
             items = list(np.asarray(info, dtype=object).reshape(-1)) if isinstance(info, np.ndarray) else list(info)
-            for it in items:
-                assert isinstance(it, dict) and 'wall_collision' in it, "every info dict needs the keys 'mover_collision' and 'wall_collision'"
-            flag = lambda it, k: bool(torch.as_tensor(it.get(k, False)).reshape(-1)[0]) if it.get(k) is not None else False  # noqa: E731
+            for it in items:  # the reference indexes both keys (PL:678-679): a dict without one of them is an error there too
+                assert isinstance(it, dict) and 'wall_collision' in it and 'mover_collision' in it, (
+                    "every info dict needs the keys 'mover_collision' and 'wall_collision'")
+            flag = lambda it, k: bool(np.asarray(torch.as_tensor(it[k]).cpu()).reshape(-1)[0])  # noqa: E731
             mc = torch.tensor([flag(it, 'mover_collision') for it in items], dtype=torch.uint8)
             wc = torch.tensor([flag(it, 'wall_collision') for it in items], dtype=torch.uint8)
-            return mc.to(self.device), wc.to(self.device), False
+            # `reward if batch_size > 1 else reward[0]` (PL:534): an array holding ONE info dict gives a scalar, like one dict
+            return mc.to(self.device), wc.to(self.device), len(items) == 1
         assert isinstance(info, dict), 'info must be an info dict or an array / list of info dicts'
         wc = torch.as_tensor(info['wall_collision'], device=self.device)
         mc_in = info.get('mover_collision')
         mc = torch.as_tensor(mc_in, device=self.device) if mc_in is not None else torch.zeros_like(wc)
         scalar = wc.ndim == 0
+        assert not scalar or mc_in is not None, "an info dict needs the keys 'mover_collision' and 'wall_collision'"  # PL:685-686
         return mc.reshape(-1).to(torch.uint8).contiguous(), wc.reshape(-1).to(torch.uint8).contiguous(), scalar
 
     def _dev_f64(self, a) -> torch.Tensor:

@@ -110,8 +110,8 @@ class VecBenchmarkPlanningEnvSubBatched:
         return OrderedDict((key, torch.cat([d[key] for d in dicts], dim=0)) for key in dicts[0])
 
     def reset(self, seed: int | None = None, options: dict[str, Any] | None = None):
-        """reset() of every sub-batch on the caller's stream (same seed: the streams are keyed by global env id); returns the
-        concatenated observation / info. ``options['mask']`` / ``options['candidates']`` are split along the env axis."""
+        """reset() of every sub-batch on the caller's stream (same seed: the streams are keyed by global env id), ordered against the
+        sub-batches' own streams on both sides; returns the concatenated observation / info. ``options['mask']`` / ``options['candidates']`` are split along the env axis."""
         self.synchronize()
         obs, infos = [], []
         for k, s in enumerate(self.subs):
@@ -125,6 +125,9 @@ class VecBenchmarkPlanningEnvSubBatched:
                     opt['candidates'] = c.reshape(c.shape[0], self.num_envs, -1)[:, self.sub_slice(k)]
             o, i = s.reset(seed=seed, options=opt)
             obs.append(o); infos.append(i)
+        # the reset kernels ran on the CALLER's stream; the next step_all_into launches on streams[k] with no event of its own, so
+        # every sub-batch's stream is made to wait for them here (a step kernel must not read state a reset is still writing)
+        self.wait_for_caller()
         return self._cat(obs), {key: torch.cat([i[key] for i in infos], dim=0) for key in infos[0]}
 
     # ------------------------------------------------------------------------------------------------------------
@@ -233,6 +236,7 @@ class VecBenchmarkPlanningEnvSubBatched:
         self.synchronize()
         for s, d in zip(self.subs, sd['subs']):
             s.load_state_dict(d)
+        self.wait_for_caller()  # (the copies ran on the caller's stream: the sub-batches' streams must see them)
 
     def close(self) -> None:
         if not self._host_only and torch.cuda.is_available():

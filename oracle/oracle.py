@@ -12,6 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libgpr_oracle.so')
+SAN_LIB = os.environ.get('GPR_ORACLE_SANITIZED_LIB')  # tests/test_host_cpu.py: the same oracle built with -fsanitize=address,undefined
 MAX_MOVERS = 16
 
 
@@ -50,8 +51,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(LIB_PATH)
+        if SAN_LIB:
+            _lib = C.CDLL(SAN_LIB)
+        else:
+            build()
+            _lib = C.CDLL(LIB_PATH)
         _lib.gpro_qpos_is_valid.restype = C.c_int64
         _lib.gpro_check_mover_collision.restype = C.c_int32
         _lib.gpro_tile_indices_mask.restype = C.c_int32

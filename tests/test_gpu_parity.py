@@ -787,6 +787,61 @@ def test_sub_batches_equal_the_whole_batch(gpr, K, kw):
     whole.close(); parts.close()
 
 
+def test_sub_batched_reset_is_ordered_before_the_next_steps(gpr):
+    """reset() runs the sub-batches' reset kernels on the CALLER's stream; step_all_into launches on the sub-batches' own streams without
+    events. reset() therefore ends by making those streams wait: reset -> step with NO host synchronisation in between must
+    equal the single batch, every time (a large batch, so that the reset kernels are still running when the step launches arrive)."""
+    E, M = 65536, 4
+    lay = np.ones((6, 6))
+    whole = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E)
+    parts = gpr.VecBenchmarkPlanningEnvSubBatched(lay, M, num_envs=E, num_sub_batches=4)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    acts = (torch.rand(3, E, 2 * M, device='cuda', generator=g) * 20 - 10)
+    z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device='cuda')  # noqa: E731
+    outs = dict(observation=z(E, whole.obs_dim), achieved_goal=z(E, 2 * M), desired_goal=z(E, 2 * M), reward=z(E), terminated=z(E, dtype=torch.uint8),
+                truncated=z(E, dtype=torch.uint8))
+    bound = parts.bind_outputs(**outs)
+    packed = [parts.pack_actions(acts[i]) for i in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(8):
+        whole.reset(seed=100 + rep)
+        for i in range(3):
+            a = whole.step(acts[i])
+        want = {k: v.clone() for k, v in a[0].items()}
+        parts.reset(seed=100 + rep)          # no synchronisation from here ...
+        for i in range(3):
+            parts.step_all_into(packed[i], bound)
+        parts.synchronize()                  # ... to here (stream order only)
+        for k in want:
+            assert torch.equal(want[k], outs[k]), (rep, k)
+        sd = parts.state_dict()
+        parts.load_state_dict(sd)            # the same for a restored checkpoint: copies on the caller's stream, steps on the sub-batches'
+        parts.step_all_into(packed[0], bound)
+        parts.synchronize()
+        b = whole.step(acts[0])
+        assert torch.equal(b[0]['achieved_goal'], outs['achieved_goal']), rep
+    whole.close(); parts.close()
+
+
+def test_step_many_refuses_a_handle_twice(gpr):
+    """two launches of ONE handle would run on two threads and race on its call counter"""
+    import ctypes as C
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((6, 6)), 4, num_envs=256)
+    env.reset(seed=0)
+    nat, lib = gpr._native, gpr._native.load()
+    act = torch.zeros(256, 8, device='cuda')
+    handles = (C.c_void_p * 2)(env._handle, env._handle)
+    acts = (C.c_void_p * 2)(act.data_ptr(), act.data_ptr())
+    outs = (C.POINTER(nat.GprStepOut) * 2)(C.pointer(env._out), C.pointer(env._out))
+    st = torch.cuda.current_stream().cuda_stream
+    streams = (C.c_void_p * 2)(st, st)
+    seed, tick = env.get_rng_state()
+    rc = lib.gpr_step_many(2, handles, acts, outs, streams)
+    assert rc == nat.E_INVALID and b'twice' in lib.gpr_last_error(env._handle)
+    assert env.get_rng_state() == (seed, tick), 'a refused call must not have launched anything'
+    env.close()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # fixtures taken from the imported reference METHODS (tests/golden/make_golden.py, round 2): observation orderings (PL:536-573)
 # and the per-cycle control decision (PL:420-450), through the C ABI
