@@ -20,8 +20,11 @@ host 3.5 us; a hipGraph of S kernel nodes costs 9.5 us per node to launch on ROC
 Closed-loop legal (every sub-batch is its own observation -> policy -> action -> step loop on its own stream) and bit
 for bit the results of the single launch (random streams are keyed by global env id). `config.single_launch` is the S = 1 number.
 
-Timed region: exactly K steps per block, R back-to-back blocks with R chosen (identically on every rank) so that the region lasts at
-least --min-seconds (0.1 s); barrier + synchronize on both sides, max over ranks. `value` = envs of all ranks x K x R / that time.
+Timed region: exactly K steps per block, R back-to-back blocks with R chosen (identically on every rank) so that a region lasts at
+least --min-seconds (2 s for the headline, --extra-seconds for every other pass); barrier + synchronize on both sides, max over ranks.
+The headline is timed over --regions (5) such regions: `value` = envs of all ranks x K x R x regions / the SUM of the regions' times,
+`config.headline_spread` = min / median / max of the regions' env-steps/s. If a region comes in more than 10 % below the best one the
+pass is rebuilt once or twice with freshly probed streams (`config.headline_attempts`) and the attempt with the best median is reported.
 HIP events are recorded on the streams the kernels are launched on.
 
 For N > 1 the env batch is sharded (one process per GPU, contiguous env ranges, random streams keyed by global env id). `value` is WEAK
@@ -60,6 +63,12 @@ def algorithmic_bytes_per_env_step(num_movers: int, precision: str = 'f32') -> i
     fp32 storage: 72 M + 17; f64 storage: 144 M + 21."""
     v = 8 if precision == 'f64' else 4
     return 18 * num_movers * v + v + 13
+
+
+def view_bytes_per_env_step(num_movers: int, precision: str = 'f32') -> int:
+    """SURVEY.md 8(d), PettingZoo per-agent views (BASELINE config 5): M rows of 4M + 2 values + M per-agent rewards, written"""
+    v = 8 if precision == 'f64' else 4
+    return v * num_movers * (4 * num_movers + 2) + v * num_movers
 
 
 def kernel_name(precision: str, movers: int, tiles: int, shape: str = 'circle', noise: bool = True, multi: bool = False) -> str:
@@ -160,7 +169,7 @@ class Pass:
     """One timed configuration on this rank: `envs` envs stepped as `sub` sub-batches (1: one handle, one launch per step)."""
 
     def __init__(self, args, rank, local_rank, world, *, envs, std_noise=1e-5, precision=None, movers=None, tiles=None, flush=None, sub=1,
-                 collision_params=None, layout=None, learn_jerk=False):
+                 collision_params=None, layout=None, learn_jerk=False, views=False):
         import numpy as np
         import torch
 
@@ -175,7 +184,14 @@ class Pass:
         kw = dict(num_envs=envs, device=self.device, std_noise=std_noise, precision=precision, env_id_offset=rank * envs, collision_params=collision_params,
                   learn_jerk=learn_jerk)
         lay = np.ones((tiles, tiles)) if layout is None else layout
-        if sub > 1:
+        self.views, self.penv = views, None
+        if views:  # BASELINE config 5: the PettingZoo-parallel env; its step kernels also write every agent's view
+            self.penv = gpr.VecBenchmarkPlanningParallelEnv(lay, self.M, num_sub_batches=sub, **kw)
+            self.env = self.penv.env
+            self.S = sub = self.penv.num_sub_batches
+            self.stream_probe = getattr(self.env, 'stream_probe', None)
+            self.streams = self.env.streams if sub > 1 else [torch.cuda.current_stream(self.device)]
+        elif sub > 1:
             self.env = gpr.VecBenchmarkPlanningEnvSubBatched(lay, self.M, num_sub_batches=sub, **kw)
             self.S = sub = self.env.num_sub_batches  # (as many as there are streams that really overlap on this device)
             self.stream_probe = self.env.stream_probe
@@ -192,12 +208,21 @@ class Pass:
         ring = (torch.rand(T, E, 2 * M, device=self.device, generator=gen, dtype=torch.float32) * (2 * lim) - lim).to(env.dtype)
         self.buf['action'].copy_(ring)  # the rollout buffer's action field doubles as the action ring
         self.outs, self.actions = [], []
+        V = 4  # per-agent views: a ring of 4 [E, M, 4M+2] slots (a [50, E, M, 4M+2] buffer would be 6.9 GB at config 5)
+        if views:
+            self.view_ring = [(torch.zeros(E, M, 4 * M + 2, dtype=env.dtype, device=self.device), torch.zeros(E, M, dtype=env.dtype, device=self.device))
+                              for _ in range(V)]
         for t in range(T):
             s = self.buf.slot(t)
-            self.outs.append(env.bind_outputs(observation=s['observation'], achieved_goal=s['achieved_goal'], desired_goal=s['desired_goal'],
-                                              reward=s['reward'], terminated=s['terminated'], truncated=s['truncated']))
+            kw_out = dict(observation=s['observation'], achieved_goal=s['achieved_goal'], desired_goal=s['desired_goal'],
+                          reward=s['reward'], terminated=s['terminated'], truncated=s['truncated'])
+            if views:
+                kw_out.update(agent_observation=self.view_ring[t % V][0], agent_reward=self.view_ring[t % V][1])
+                self.outs.append(self.penv.bind_outputs(**kw_out))
+            else:
+                self.outs.append(env.bind_outputs(**kw_out))
             self.actions.append(env.pack_actions(self.buf['action'][t]) if sub > 1 else self.buf['action'][t])
-        env.reset(seed=0)
+        (self.penv or env).reset(seed=0)
         # desynchronise the episode phases (TimeLimit counters), as a long-running job would be
         el = torch.randint(0, T, (E,), device=self.device, generator=gen, dtype=torch.int32)
         if sub > 1:
@@ -232,36 +257,46 @@ class Pass:
             dist.barrier()
             torch.cuda.synchronize(self.device)
 
-    def run(self, steps, warmup, min_seconds):
-        """-> (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region [the longest of the streams the
-        kernels ran on], R). R starts at 1 and grows (identically on every rank: it follows the all-reduced wall time) until the region
-        lasts min_seconds."""
+    def run(self, steps, warmup, min_seconds, regions=1):
+        """-> (list of (wall seconds over R x steps steps [max over ranks], HIP-event ms over the same region [the longest of the streams
+        the kernels ran on]) for `regions` timed regions, R). R starts at 1 and grows (identically on every rank: it follows the
+        all-reduced wall time) until a region lasts min_seconds; the calibration regions are not reported."""
         import torch
-        reps = 1
+
+        def one_region(reps):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.streams]
+            self.sync()
+            for (e0, _), st in zip(ev, self.streams):
+                e0.record(st)  # on the stream the kernels are launched on
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.do_steps(steps)
+            for (_, e1), st in zip(ev, self.streams):
+                e1.record(st)
+            self.sync()
+            wall = time.perf_counter() - t0
+            gpu_ms = max(e0.elapsed_time(e1) for e0, e1 in ev)
+            if self.world > 1:
+                import torch.distributed as dist
+                w = torch.tensor([wall], device=self.device, dtype=torch.float64)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                wall = float(w.item())
+            return wall, gpu_ms
+
+        reps, out = 1, []
         with torch.cuda.device(self.device):
             self.do_steps(warmup)
-            for _ in range(6):
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.streams]
-                self.sync()
-                for (e0, _), st in zip(ev, self.streams):
-                    e0.record(st)  # on the stream the kernels are launched on
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    self.do_steps(steps)
-                for (_, e1), st in zip(ev, self.streams):
-                    e1.record(st)
-                self.sync()
-                wall = time.perf_counter() - t0
-                gpu_ms = max(e0.elapsed_time(e1) for e0, e1 in ev)
-                if self.world > 1:
-                    import torch.distributed as dist
-                    w = torch.tensor([wall], device=self.device, dtype=torch.float64)
-                    dist.all_reduce(w, op=dist.ReduceOp.MAX)
-                    wall = float(w.item())
+            for _ in range(8):
+                wall, gpu_ms = one_region(reps)
                 if wall >= min_seconds:
+                    out.append((wall, gpu_ms))
                     break
-                reps = int(math.ceil(reps * min_seconds / max(wall, 1e-6) * 1.25))
-        return wall, gpu_ms, reps
+                reps = int(math.ceil(reps * min_seconds / max(wall, 1e-6) * 1.15))
+            else:
+                out.append((wall, gpu_ms))
+            while len(out) < regions:
+                out.append(one_region(reps))
+        return out, reps
 
     def done_fraction(self):
         """mean over the rollout slots that were actually written of (terminated | truncated)"""
@@ -276,18 +311,39 @@ class Pass:
         torch.cuda.empty_cache()
 
 
-def timed(args, rank, local_rank, world, steps=None, warmup=None, **kw):
+def timed(args, rank, local_rank, world, steps=None, warmup=None, min_seconds=None, regions=1, **kw):
     p = Pass(args, rank, local_rank, world, **kw)
-    wall, gpu_ms, reps = p.run(steps or args.steps, args.warmup if warmup is None else warmup, args.min_seconds)
-    n = (steps or args.steps) * reps
+    K = steps or args.steps
+    regs, reps = p.run(K, args.warmup if warmup is None else warmup, args.extra_seconds if min_seconds is None else min_seconds, regions)
+    n1 = K * reps                                   # env-steps of the rank's batch per region
+    n, wall, gpu_ms = n1 * len(regs), sum(w for w, _ in regs), sum(g for _, g in regs)
+    rates = sorted(world * p.E * n1 / w for w, _ in regs)
     # step_us: HIP-event time per env-step of the rank. Every stream runs its n launches back to back, so this is also the average
     # duration of ONE launch as a kernel trace shows it -- S of them (one per sub-batch) in flight at any time
-    res = {'wall': wall, 'gpu_ms': gpu_ms, 'reps': reps, 'n_steps': n, 'step_us': gpu_ms * 1e3 / n,
-           'stream_probe': getattr(p.env, 'stream_probe', None) if p.S > 1 else getattr(p, 'stream_probe', None),
-           'sub_batches': p.S, 'envs_per_launch': p.E // p.S,
+    res = {'wall': wall, 'gpu_ms': gpu_ms, 'reps': reps, 'n_steps': n, 'step_us': gpu_ms * 1e3 / n, 'regions': len(regs),
+           'region_seconds': [w for w, _ in regs], 'region_step_us': [g * 1e3 / n1 for _, g in regs],
+           'rate_min': rates[0], 'rate_median': rates[len(rates) // 2], 'rate_max': rates[-1],
+           'stream_probe': getattr(p, 'stream_probe', None),
+           'sub_batches': p.S, 'envs_per_launch': p.E // p.S, 'movers': p.M, 'views': p.views,
            'env_steps_per_s': world * p.E * n / wall, 'done_fraction': p.done_fraction(), 'rollout_bytes': p.buf.nbytes}
     p.close()
     return res
+
+
+def timed_headline(args, rank, local_rank, world, **kw):
+    """the headline pass: --regions timed regions of >= --min-seconds each. A region more than 10 % below the best one means the
+    launches did not overlap as probed (streams sharing a hardware queue with somebody else's work): the pass is rebuilt with freshly
+    probed streams, at most twice, and the attempt with the best median is kept. Every attempt is listed in the line."""
+    attempts = []
+    for _ in range(3):
+        r = timed(args, rank, local_rank, world, min_seconds=args.min_seconds, regions=args.regions, **kw)
+        attempts.append(r)
+        if r['rate_min'] >= 0.9 * r['rate_max']:
+            break
+    best = max(attempts, key=lambda r: r['rate_median'])
+    best['attempts'] = [{'env_steps_per_s': a['env_steps_per_s'], 'min': a['rate_min'], 'median': a['rate_median'], 'max': a['rate_max'],
+                         'stream_probe': a['stream_probe'], 'sub_batches': a['sub_batches']} for a in attempts]
+    return best
 
 
 def timed_rollout_launch(args, rank, local_rank, world, envs, n_steps=T_ROLLOUT):
@@ -329,9 +385,9 @@ def timed_rollout_launch(args, rank, local_rank, world, envs, n_steps=T_ROLLOUT)
                 w = torch.tensor([wall], device=device, dtype=torch.float64)
                 dist.all_reduce(w, op=dist.ReduceOp.MAX)
                 wall = float(w.item())
-            if wall >= args.min_seconds:
+            if wall >= args.extra_seconds:
                 break
-            launches = int(math.ceil(launches * args.min_seconds / max(wall, 1e-6) * 1.25))
+            launches = int(math.ceil(launches * args.extra_seconds / max(wall, 1e-6) * 1.25))
     env.close()
     n = launches * n_steps
     us = wall / n * 1e6
@@ -393,15 +449,16 @@ def cpu_baseline(args):
             'sample': f'{E} envs x {n} steps ({dt:.1f} s), oracle/gpr_oracle.c (fp64, reference-literal loops), {threads} pthreads'}
 
 
-def roofline_of(r, precision, movers, tiles, envs):
+def roofline_of(r, precision, movers, tiles, envs=None, shape='circle'):
     """the roofline block of one timed pass. With S sub-batches the rank has S launches in flight, one per stream, each stream's launches
     back to back: `kernel_us` = a stream's HIP-event time / its launches = what a kernel trace shows as the average duration of one launch,
-    and achieved = S x algorithmic bytes per launch / kernel_us (= the bytes of one env-step of all the rank's envs / the time it takes)."""
-    B = algorithmic_bytes_per_env_step(movers, precision)
+    and achieved = S x algorithmic bytes per launch / kernel_us (= the bytes of one env-step of all the rank's envs / the time it takes).
+    Passes through the PettingZoo-parallel env (`views`) add the per-agent rows the same kernel writes."""
+    B = algorithmic_bytes_per_env_step(movers, precision) + (view_bytes_per_env_step(movers, precision) if r.get('views') else 0)
     S, epl = r['sub_batches'], r['envs_per_launch']
     kernel_us = r['step_us']
     achieved = S * B * epl / (kernel_us * 1e-6) / 1e9
-    name = kernel_name(precision, movers, tiles)
+    name = kernel_name(precision, movers, tiles, shape=shape)
     tr = committed_profile('hbm_traffic', name, epl)
     frac = achieved / HBM_PEAK_GBS
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': frac,
@@ -409,6 +466,12 @@ def roofline_of(r, precision, movers, tiles, envs):
             'envs_per_launch': epl, 'algorithmic_bytes_per_env_step': B, 'algorithmic_bytes_per_launch': B * epl,
             'achieved_is': 'launches_in_flight x algorithmic_bytes_per_launch / kernel_us',
             'valu': valu_block(name, epl, kernel_us, S, frac)}
+
+
+def config_row(r, precision, movers, tiles, what):
+    """one BASELINE.json configuration in the line: what was timed, its rate and its own roofline block"""
+    return {'what': what, 'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us'], 'sub_batches': r['sub_batches'],
+            'per_agent_views_written': bool(r.get('views')), 'roofline': roofline_of(r, precision, movers, tiles)}
 
 
 def main():
@@ -421,7 +484,9 @@ def main():
     ap.add_argument('--tiles', type=int, default=6)
     ap.add_argument('--precision', default='f32', choices=['f32', 'f32_f64acc', 'f64'])
     ap.add_argument('--sub-batches', type=int, default=4, help='sub-batches (handles + HIP streams) the rank\'s envs are stepped as; 1 = one launch per step')
-    ap.add_argument('--min-seconds', type=float, default=0.1, help='minimum length of every timed region (blocks of --steps are repeated)')
+    ap.add_argument('--min-seconds', type=float, default=2.0, help='minimum length of each timed region of the HEADLINE pass (blocks of --steps are repeated)')
+    ap.add_argument('--regions', type=int, default=5, help='timed regions of the headline pass (value = all their env-steps / all their time; spread reported)')
+    ap.add_argument('--extra-seconds', type=float, default=0.15, help='minimum length of the timed region of every other pass')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline pass only (profiling runs)')
@@ -458,14 +523,17 @@ def main():
     E, M, K, S = args.envs_per_gpu, args.movers, args.steps, max(1, args.sub_batches)
     while E % S:
         S //= 2
-    head = timed(args, rank, local_rank, world, envs=E, sub=S)                    # headline: the reference's default noise
+    head = timed_headline(args, rank, local_rank, world, envs=E, sub=S)           # headline: the reference's default noise
     cfg = {
         'workload': f'BenchmarkPlanningEnv, {M} movers, layout ones({args.tiles},{args.tiles}), {E} envs per GPU, num_cycles 40, '
                     'std_noise 1e-5 (reference default), TimeLimit 50 with desynchronised episode phases, same-step auto-reset, '
                     'actions ~ U(-10, 10)',
         'envs_per_gpu': E, 'num_movers': M, 'parallelism': f'env-shard x{world}, no collective in step()',
-        'sub_batches': f'{S} sub-batches of {E // S} envs per GPU, one handle + one HIP stream each, {S} launches per env-step issued by one gpr_step_many call',
-        'timed_steps': head['n_steps'], 'timed_blocks': head['reps'], 'timed_seconds': head['wall'],
+        'sub_batches': f"{head['sub_batches']} sub-batches of {E // head['sub_batches']} envs per GPU, one handle + one HIP stream each, {head['sub_batches']} launches per env-step issued by one gpr_step_many call",
+        'timed_steps': head['n_steps'], 'timed_blocks': head['reps'], 'timed_regions': head['regions'], 'timed_seconds': head['wall'],
+        'headline_spread': {'what': 'env-steps/s of each timed region of the reported attempt', 'min': head['rate_min'], 'median': head['rate_median'],
+                            'max': head['rate_max'], 'region_seconds': head['region_seconds'], 'region_kernel_us': head['region_step_us']},
+        'headline_attempts': head['attempts'],
         'done_fraction_per_step': head['done_fraction'], 'stream_probe': head['stream_probe'],
     }
     if backend:
@@ -478,6 +546,8 @@ def main():
         'config': cfg,
         'roofline': roofline_of(head, args.precision, M, args.tiles, E),
     }
+    if world == 1:
+        line['strong_value'] = head['env_steps_per_s']  # (one GPU: the strong shape IS the weak one)
 
     if not args.no_extras:
         if S > 1:
@@ -494,6 +564,7 @@ def main():
             while Es % Ss:
                 Ss //= 2
             st = timed(args, rank, local_rank, world, envs=Es, sub=Ss)
+            line['strong_value'] = st['env_steps_per_s']  # BASELINE's metric read as STRONG scaling: 65 536 envs in total over the N GPUs
             cfg['strong_scaling'] = {'envs_total': Es * world, 'envs_per_gpu': Es, 'sub_batches': Ss, 'env_steps_per_s': st['env_steps_per_s'],
                                      'ms_per_step': st['wall'] / st['n_steps'] * 1e3, 'step_us': st['step_us'],
                                      'rollout_launch': timed_rollout_launch(args, rank, local_rank, world, Es)}
@@ -506,19 +577,31 @@ def main():
             cfg['other_batch_sizes'] = sizes
             cfg['rollout_launch'] = {str(n): timed_rollout_launch(args, rank, local_rank, world, n) for n in (8192, E)}
             if (M, args.tiles, args.precision) == (4, 6, 'f32'):
-                # BASELINE.json's other configurations at the size ONE GPU of its node gets, and whole (parity-test cases, not the headline;
-                # config 2 = other_batch_sizes['4096'])
+                # BASELINE.json's other configurations AS STATED, at the size ONE GPU of its 8-GPU node gets and whole, each with its own
+                # roofline block (parity-test cases, not the headline). Config 5 goes through the PettingZoo-parallel env: the per-agent
+                # views (4 M (4M+2) + 4 M bytes per env-step) are written inside the timed region by the same kernel.
                 shapes = {}
-                for name, kw in (('config4_shard: 8 movers x 8192 envs', dict(envs=8192, movers=8, tiles=8)),
-                                 ('config4: 8 movers x 65536 envs', dict(envs=65536, movers=8, tiles=8)),
-                                 ('config5_shard: 16 movers x 4096 envs', dict(envs=4096, movers=16, tiles=10)),
-                                 ('config5: 16 movers x 32768 envs', dict(envs=32768, movers=16, tiles=10))):
+                for name, kw, what in (
+                        ('config2: 4 movers x 4096 envs', dict(envs=4096, movers=4, tiles=6), 'BenchmarkPlanningEnv, 4 movers, 4096 envs on 1 MI355X'),
+                        ('config4_shard: 8 movers x 8192 envs', dict(envs=8192, movers=8, tiles=8), 'BenchmarkPlanningEnv, 8 movers: the 8192 envs one of 8 GPUs gets'),
+                        ('config4: 8 movers x 65536 envs', dict(envs=65536, movers=8, tiles=8), 'BenchmarkPlanningEnv, 8 movers, all 65536 envs on one GPU'),
+                        ('config5_shard: 16 movers x 4096 envs, PettingZoo parallel', dict(envs=4096, movers=16, tiles=10, views=True),
+                         'VecBenchmarkPlanningParallelEnv, 16 movers: the 4096 envs one of 8 GPUs gets, per-agent views written'),
+                        ('config5: 16 movers x 32768 envs, PettingZoo parallel', dict(envs=32768, movers=16, tiles=10, views=True),
+                         'VecBenchmarkPlanningParallelEnv, 16 movers, all 32768 envs on one GPU, per-agent views written'),
+                        ('config5_single_agent_shard: 16 movers x 4096 envs', dict(envs=4096, movers=16, tiles=10), 'the same envs without the per-agent views'),
+                        ('config5_single_agent: 16 movers x 32768 envs', dict(envs=32768, movers=16, tiles=10), 'the same envs without the per-agent views')):
                     r = timed(args, rank, local_rank, world, steps=100, warmup=40, sub=S, **kw)
-                    shapes[name] = {'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us'], 'sub_batches': r['sub_batches'],
-                                    'hbm_frac': algorithmic_bytes_per_env_step(kw['movers'], 'f32') * kw['envs'] / (r['step_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS}
-                for nm in (1, 2):
+                    shapes[name] = config_row(r, 'f32', kw['movers'], kw['tiles'], what)
+                for nm, B in ((1, 273), (2, 401)):
                     r = timed_pushing(args, local_rank, 4096, nm)
-                    shapes[f'config3: pushing env, {nm} mover(s) x 4096 envs, one launch per step'] = {'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us']}
+                    shapes[f'config3: pushing env, {nm} mover(s) x 4096 envs, one launch per step'] = {
+                        'what': 'BenchmarkPushingEnv (contact model gpr-push-v2, engine-defined: parity unpinned)' + (' -- the reference has 1 mover' if nm == 1 else ' -- BASELINE config 3'),
+                        'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us'],
+                        'roofline': {'bound': 'hbm', 'achieved': B * 4096 / (r['step_us'] * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                     'frac': B * 4096 / (r['step_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'gpr::k_push', 'kernel_us': r['step_us'],
+                                     'algorithmic_bytes_per_env_step': B,
+                                     'note': 'SURVEY 8(d): 4 (30 + 34) + 17 B with one mover; + 13 state values read and written, 2 action and 4 observation values per further mover'}}
                 cfg['baseline_configs'] = shapes
             if args.precision == 'f32':
                 # the reference's own arithmetic (float64): its own roofline block, kernel name and bytes

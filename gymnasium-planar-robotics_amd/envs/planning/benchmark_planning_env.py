@@ -228,18 +228,25 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
     # zero-copy rollout collection: let the kernel write a step's outputs straight into caller-owned tensors
     # ------------------------------------------------------------------------------------------------------------
     def bind_outputs(self, observation: torch.Tensor, achieved_goal: torch.Tensor, desired_goal: torch.Tensor, reward: torch.Tensor,
-                     terminated: torch.Tensor, truncated: torch.Tensor) -> _native.GprStepOut:
+                     terminated: torch.Tensor, truncated: torch.Tensor, agent_observation: torch.Tensor | None = None,
+                     agent_reward: torch.Tensor | None = None) -> _native.GprStepOut:
         """Describe an alternative set of output tensors (e.g. slot ``t`` of a ``distributed.RolloutBuffer``) for ``step_into``.
-        The info flags and ``final_obs`` keep going to the env's own tensors."""
+        The info flags and ``final_obs`` keep going to the env's own tensors. ``agent_observation`` ``[E, M, 4M+2]`` / ``agent_reward``
+        ``[E, M]``: the per-agent views of the PettingZoo-parallel layer, written by the step kernel's epilogue (both or neither)."""
         E, M = self.num_envs, self.num_movers
-        for t, shape, dt in ((observation, (E, self.obs_dim), self.dtype), (achieved_goal, (E, 2 * M), self.dtype),
-                             (desired_goal, (E, 2 * M), self.dtype), (reward, (E,), self.dtype), (terminated, (E,), torch.uint8),
-                             (truncated, (E,), torch.uint8)):
+        checks = [(observation, (E, self.obs_dim), self.dtype), (achieved_goal, (E, 2 * M), self.dtype), (desired_goal, (E, 2 * M), self.dtype),
+                  (reward, (E,), self.dtype), (terminated, (E,), torch.uint8), (truncated, (E,), torch.uint8)]
+        assert (agent_observation is None) == (agent_reward is None), 'bind both agent_observation and agent_reward or neither'
+        if agent_observation is not None:
+            checks += [(agent_observation, (E, M, 4 * M + 2), self.dtype), (agent_reward, (E, M), self.dtype)]
+        for t, shape, dt in checks:
             assert tuple(t.shape) == shape and t.dtype == dt and t.device == self.device and t.is_contiguous(), (tuple(t.shape), t.dtype)
         o = _native.GprStepOut()
         C.memmove(C.byref(o), C.byref(self._out), C.sizeof(o))
         o.observation_dev, o.achieved_goal_dev, o.desired_goal_dev = observation.data_ptr(), achieved_goal.data_ptr(), desired_goal.data_ptr()
         o.reward_dev, o.terminated_dev, o.truncated_dev = reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr()
+        if agent_observation is not None:
+            o.agent_observation_dev, o.agent_reward_dev = agent_observation.data_ptr(), agent_reward.data_ptr()
         return o
 
     def step_into(self, action: torch.Tensor, out: _native.GprStepOut) -> None:

@@ -823,6 +823,43 @@ def test_sub_batched_reset_is_ordered_before_the_next_steps(gpr):
     whole.close(); parts.close()
 
 
+def test_parallel_env_with_sub_batches_equals_one_launch(gpr):
+    """VecBenchmarkPlanningParallelEnv(num_sub_batches=K): per-agent observations / rewards / flags bit for bit those of the one-launch
+    env, through step() (dict of agents) and through the bound outputs + step_all_into (bench.py's config-5 rows)"""
+    E, M, n = 2048, 16, 10
+    lay = np.ones((n, n))
+    one = gpr.VecBenchmarkPlanningParallelEnv(lay, M, num_envs=E)
+    sub = gpr.VecBenchmarkPlanningParallelEnv(lay, M, num_envs=E, num_sub_batches=4)
+    assert sub.num_sub_batches >= 2
+    oa, _ = one.reset(seed=9); ob, _ = sub.reset(seed=9)
+    for a in one.agents:
+        assert torch.equal(oa[a], ob[a]), a
+    g = torch.Generator(device='cuda').manual_seed(3)
+    n_done = 0
+    for t in range(30):
+        act = (torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10)
+        ra = one.step(act); rb = sub.step(act)
+        for a in one.agents:
+            assert torch.equal(ra[0][a], rb[0][a]) and torch.equal(ra[1][a], rb[1][a]), (t, a)
+        assert torch.equal(ra[2]['mover_0'], rb[2]['mover_0']) and torch.equal(ra[3]['mover_0'], rb[3]['mover_0'])
+        n_done += int((ra[2]['mover_0'] | ra[3]['mover_0']).sum())
+    assert n_done > E
+    assert torch.equal(one.state(), sub.state())
+    # bound outputs: the views land in caller-owned tensors
+    z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device='cuda')  # noqa: E731
+    outs = dict(observation=z(E, 2 * M), achieved_goal=z(E, 2 * M), desired_goal=z(E, 2 * M), reward=z(E), terminated=z(E, dtype=torch.uint8),
+                truncated=z(E, dtype=torch.uint8), agent_observation=z(E, M, 4 * M + 2), agent_reward=z(E, M))
+    bound = sub.bind_outputs(**outs)
+    for t in range(5):
+        act = (torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10)
+        ra = one.step(act)
+        sub.env.wait_for_caller()
+        sub.env.step_all_into(sub.env.pack_actions(act), bound)
+        sub.env.synchronize()
+        assert torch.equal(one._agent_obs, outs['agent_observation']) and torch.equal(one._agent_reward, outs['agent_reward']), t
+    one.close(); sub.close()
+
+
 def test_step_many_refuses_a_handle_twice(gpr):
     """two launches of ONE handle would run on two threads and race on its call counter"""
     import ctypes as C
