@@ -31,7 +31,7 @@ For N > 1 the env batch is sharded (one process per GPU, contiguous env ranges, 
 scaling (65 536 envs per GPU); BASELINE.json's STRONG shape (65 536 envs in total) is timed in the same run (`config.strong_scaling`).
 step() has no exchange step. What crosses xGMI is the rollout flush: `config.rollout_gather` times, at the strong shape, ONE
 `all_gather_into_tensor` of every rank's [50, E/N, .] rollout buffer (north_star's collective), the learner-minibatch gather and the
-48-byte counters all-reduce, each inside a timed region of env-steps. Rank 0 prints one JSON line.
+64-byte counters all-reduce, each inside a timed region of env-steps. Rank 0 prints one JSON line.
 
 Workload (BASELINE.json): BenchmarkPlanningEnv, 4 movers, layout ones(6,6), reference defaults (num_cycles 40,
 dt 1e-3, v_max 2, a_max 10, circle r 0.11, std_noise 1e-5, TimeLimit 50), actions ~ U(-a_max, a_max).
@@ -647,7 +647,7 @@ def main():
             fenced(p, lambda: p.buf.gather_minibatch(min(1024, p.E)))  # ONE all-gather of a learner-sized [50, 1024, .] slice
 
         def flush_counters(p):
-            p.env.all_reduce_episode_counters()  # ONE all_reduce of six uint64 counters; rollouts stay sharded
+            p.env.all_reduce_episode_counters()  # ONE all_reduce of eight uint64 counters; rollouts stay sharded
 
         base = timed(args, rank, local_rank, world, envs=Es, sub=Ss, steps=max(100, K // 4))
         g = timed(args, rank, local_rank, world, envs=Es, sub=Ss, steps=max(100, K // 4), flush=flush_all)
@@ -657,8 +657,8 @@ def main():
         per_flush = lambda r: (r['wall'] / r['n_steps'] - base['wall'] / base['n_steps']) * T_ROLLOUT * 1e3  # noqa: E731
         cfg['rollout_gather'] = {
             'what': f'at the strong shape ({Es} envs per GPU, {world} ranks), every {T_ROLLOUT} env-steps inside the timed region: ONE all_gather_into_tensor of '
-                    'every rank\'s [50, E/N, .] rollout buffer; or ONE all-gather of a [50, 1024, .] learner minibatch; or ONE all_reduce of the six '
-                    'episode counters (48 B)',
+                    'every rank\'s [50, E/N, .] rollout buffer; or ONE all-gather of a [50, 1024, .] learner minibatch; or ONE all_reduce of the eight '
+                    'episode counters (64 B)',
             'status': 'ok', 'bytes_per_rank_per_flush': g['rollout_bytes'],
             'env_steps_per_s': g['env_steps_per_s'], 'ms_per_flush': per_flush(g),
             'no_flush_env_steps_per_s': base['env_steps_per_s'],

@@ -14,11 +14,11 @@ OK, E_INVALID, E_HIP, E_UNBOUND, E_UNSUPPORTED = 0, -1, -2, -3, -4
 SHAPE = {'circle': 0, 'box': 1}
 AUTORESET = {'disabled': 0, 'same_step': 1, 'next_step': 2}
 PRECISION = {'f32': 0, 'f32_f64acc': 1, 'f64': 2}
-COUNTERS = ('episodes', 'terminated', 'truncated', 'success', 'wall_collision', 'mover_collision')  # GPR_CNT_*
+COUNTERS = ('episodes', 'terminated', 'truncated', 'success', 'wall_collision', 'mover_collision', 'reset_exhausted', 'actions_clipped')  # GPR_CNT_*
 
 EXPORTS = (
     'gpr_version', 'gpr_last_error', 'gpr_create', 'gpr_destroy', 'gpr_bind_state', 'gpr_seed', 'gpr_get_rng_state', 'gpr_set_rng_state',
-    'gpr_reset', 'gpr_reset_candidates', 'gpr_step', 'gpr_step_many', 'gpr_streams_overlap', 'gpr_step_n', 'gpr_enable_counters', 'gpr_read_counters',
+    'gpr_reset', 'gpr_reset_candidates', 'gpr_step', 'gpr_step_many', 'gpr_streams_overlap', 'gpr_step_n', 'gpr_enable_counters', 'gpr_read_counters', 'gpr_count_clipped_actions', 'gpr_read_diagnostics', 'gpr_get_mover_state',
     'gpr_compute_reward', 'gpr_agent_views', 'gpr_push_configure', 'gpr_push_reset', 'gpr_push_reset_opts', 'gpr_push_reset_candidates', 'gpr_push_step', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
     'gpr_get_2D_rect_vertices', 'gpr_check_rectangles_intersect', 'gpr_ensure_max_dyn_val',
 )
@@ -103,6 +103,9 @@ def load() -> C.CDLL:
     lib.gpr_set_rng_state.argtypes = [vp, u64, u64]
     lib.gpr_enable_counters.argtypes = [vp, i32]
     lib.gpr_read_counters.argtypes = [vp, vp, vp]
+    lib.gpr_count_clipped_actions.argtypes = [vp, i32]
+    lib.gpr_read_diagnostics.argtypes = [vp, C.POINTER(u64), vp]
+    lib.gpr_get_mover_state.argtypes = [vp, i32, i32, vp, dbl, i32, vp, vp]
     lib.gpr_push_configure.argtypes = [vp, C.POINTER(GprPushParams), C.POINTER(GprPushState)]
     lib.gpr_push_reset.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_push_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]

@@ -54,6 +54,8 @@ struct gpr_env {
     uint32_t *counters = nullptr;  // [waves][GPR_NUM_COUNTERS] per-wavefront episode counters (gpr_enable_counters)
     size_t counter_rows = 0;
     bool counters_on = false;
+    uint32_t *diag = nullptr;      // [4] device words: pending reset-exhausted / clipped counts, and what gpr_read_counters has moved out so far
+    bool count_clipped = false;    // gpr_count_clipped_actions
     PushCst<float> push_f{};
     PushCst<double> push_d{};
     PushPtrs push_ptrs{};
@@ -224,6 +226,7 @@ hipError_t ensure_normal_tables() {
     if (he == hipSuccess) he = set_normal_table_env<float, double>(d);
     if (he == hipSuccess) he = set_normal_table_env<double, double>(d);
     if (he == hipSuccess) he = set_normal_table_push(d);
+    if (he == hipSuccess) he = set_normal_table_ops(d);
     if (he == hipSuccess) ready.push_back(dev);
     return he;
 }
@@ -253,6 +256,7 @@ KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
     P.pos = e->state.pos_dev; P.vel = e->state.vel_dev; P.acc = e->state.acc_dev; P.goal = e->state.goal_dev;
     P.elapsed = e->state.elapsed_dev;
     P.counters = e->counters_on ? e->counters : nullptr;
+    P.diag = e->diag; P.count_clipped = e->count_clipped ? 1 : 0;
     P.n_steps = 1;
     if (out) {
         P.obs = out->observation_dev; P.ag = out->achieved_goal_dev; P.dg = out->desired_goal_dev; P.reward = out->reward_dev;
@@ -460,6 +464,15 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
         gpr_destroy(e);
         return GPR_E_UNSUPPORTED;
     }
+    {
+        hipError_t he = hipMalloc(reinterpret_cast<void **>(&e->diag), 4 * sizeof(uint32_t));
+        if (he == hipSuccess) he = hipMemset(e->diag, 0, 4 * sizeof(uint32_t));
+        if (he != hipSuccess) {
+            g_create_error = std::string("gpr_create: diagnostics words: ") + hipGetErrorString(he);
+            gpr_destroy(e);
+            return GPR_E_HIP;
+        }
+    }
     KParams &P = e->base;
     P.E = c.num_envs; P.env_id_offset = c.env_id_offset;
     P.M = c.num_movers; P.Tx = c.num_tiles_x; P.Ty = c.num_tiles_y; P.c_shape = c.c_shape;
@@ -506,6 +519,7 @@ void gpr_destroy(gpr_env *env) {
     }
 #endif
     if (env->counters) (void)hipFree(env->counters);
+    if (env->diag) (void)hipFree(env->diag);
     for (auto &sl : env->step_slots) {
         if (sl.busy) (void)hipEventSynchronize(sl.done);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -577,8 +591,46 @@ int gpr_read_counters(gpr_env *env, uint64_t *totals_dev, void *hip_stream) {
     if (!env || !totals_dev) return fail(env, GPR_E_INVALID, "gpr_read_counters: NULL argument");
     if (!env->counters) return fail(env, GPR_E_UNBOUND, "gpr_read_counters: call gpr_enable_counters first");
     if (const int rc = check_device(env, "gpr_read_counters")) return rc;
-    hipError_t he = launch_counter_reduce(env->counters, (int64_t)env->counter_rows, totals_dev, as_stream(hip_stream));
+    hipError_t he = launch_counter_reduce(env->counters, (int64_t)env->counter_rows, totals_dev, env->diag, as_stream(hip_stream));
     return he == hipSuccess ? GPR_OK : fail_hip(env, he, "counter reduce kernel launch");
+}
+
+int gpr_count_clipped_actions(gpr_env *env, int32_t enable) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_count_clipped_actions: NULL handle");
+    env->count_clipped = enable != 0;
+    return GPR_OK;
+}
+
+int gpr_read_diagnostics(gpr_env *env, uint64_t *totals_host, void *hip_stream) {
+    if (!env || !totals_host) return fail(env, GPR_E_INVALID, "gpr_read_diagnostics: NULL argument");
+    if (const int rc = check_device(env, "gpr_read_diagnostics")) return rc;
+    uint32_t h[4] = {0, 0, 0, 0};
+    // ordered behind the kernels of `hip_stream`; the host waits for them (this is a diagnostic read, not a hot-path call)
+    hipError_t he = hipMemcpyAsync(h, env->diag, sizeof(h), hipMemcpyDeviceToHost, as_stream(hip_stream));
+    if (he == hipSuccess) he = hipStreamSynchronize(as_stream(hip_stream));
+    if (he != hipSuccess) return fail_hip(env, he, "gpr_read_diagnostics");
+    totals_host[0] = (uint64_t)h[0] + h[2];
+    totals_host[1] = (uint64_t)h[1] + h[3];
+    return GPR_OK;
+}
+
+int gpr_get_mover_state(gpr_env *env, int32_t which, int32_t n_sel, const int32_t *mover_idx_dev, double z_report, int32_t add_noise, void *out_dev,
+                        void *hip_stream) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_get_mover_state: NULL handle");
+    if (!env->bound) return fail(env, GPR_E_UNBOUND, "gpr_get_mover_state: call gpr_bind_state first");
+    if (which < 0 || which > 2 || n_sel < 1 || !mover_idx_dev || !out_dev) return fail(env, GPR_E_INVALID, "gpr_get_mover_state: bad argument");
+    if (const int rc = check_device(env, "gpr_get_mover_state")) return rc;
+    KParams P = make_params(env, nullptr, true);
+    const void *rot = env->push_ready ? env->push_ptrs.mover_rot : nullptr;
+    hipError_t he;
+    switch (env->cfg.precision) {
+        case GPR_PRECISION_F32: he = launch_mover_state<float, float>(P, which, n_sel, mover_idx_dev, z_report, add_noise, rot, out_dev, as_stream(hip_stream)); break;
+        case GPR_PRECISION_F32_F64ACC: he = launch_mover_state<float, double>(P, which, n_sel, mover_idx_dev, z_report, add_noise, rot, out_dev, as_stream(hip_stream)); break;
+        default: he = launch_mover_state<double, double>(P, which, n_sel, mover_idx_dev, z_report, add_noise, rot, out_dev, as_stream(hip_stream)); break;
+    }
+    if (he != hipSuccess) return fail_hip(env, he, "mover state kernel launch");
+    if (add_noise) env->tick += 1;  // (a noisy read consumes random numbers, like the reference's rng_noise.normal)
+    return GPR_OK;
 }
 
 int gpr_reset(gpr_env *env, const uint8_t *mask_dev, const gpr_step_out *out, void *hip_stream) {

@@ -16,7 +16,7 @@
 
 namespace gpr {
 
-constexpr uint32_t KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4;
+constexpr uint32_t KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4, KIND_GETTER_NOISE = 5;
 #ifndef GPR_BLOCK
 #define GPR_BLOCK 256
 #endif
@@ -67,6 +67,11 @@ struct KParams {
     int32_t n_steps;            // gpr_step_n: env-steps per launch (1: gpr_step) ...
     const struct KParams *step_params;  // ... and (host side only) the device array of the n per-step parameter blocks
     uint32_t *counters;         // [wavefronts][6] episode counters (include/gpr.h: GPR_CNT_*), NULL = not counting
+    // diagnostics the reference prints as warnings: [0] reset searches that ran out of max_reset_trials (PL:371-375, 397-401: the last,
+    // INVALID candidate then stands), [1] env-steps whose action lay outside the action space and was clipped (BE:1871-1873; counted
+    // only when count_clipped is set). Rare events: one device-scope atomic add per event / per wavefront with an event; never NULL.
+    uint32_t *diag;
+    int32_t count_clipped;
     unsigned int *wave_timing;  // debug builds (-DGPR_WAVE_TIMING): 8 words per wavefront of the step kernel, else NULL
 };
 // BenchmarkPushingEnv additions (include/gpr.h: gpr_push_params), in the compute type
@@ -206,6 +211,10 @@ template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32
     const double rad = tab[r >> 16];
     const double2 cs = reinterpret_cast<const double2 *>(tab + 65536)[r & 0xFFFFu];
     return R2<double>{rad * cs.x, rad * cs.y};
+}
+
+__device__ __forceinline__ void diag_add(const KParams &P, int which, uint32_t n) {
+    __hip_atomic_fetch_add(P.diag + which, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // a noisy 2-vector reading: value + sigma * N(0,1) per component (BE:828,841), from normal pair q of the lane's stream

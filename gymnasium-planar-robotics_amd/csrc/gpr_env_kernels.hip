@@ -205,6 +205,9 @@ __device__ __forceinline__ Obs<RT> group_reset(const KParams &P, const Tables<RT
             }
         }
         if ((S != 1) & pending) cand = candidate(key, P.max_reset_trials - 1);  // trials exhausted: the last candidate stands
+        // ... and it is INVALID: the reference keeps looping and warns every 100 trials (PL:371-375, 397-401); the engine counts the
+        // search (GPR_CNT_RESET_EXHAUSTED), the host layer turns a non-zero count into that warning
+        if (!(SCRIPT && scripted) && (pending & need & live & (mv == 0) & (slot == 0))) diag_add(P, 0, 1u);
         if (need) { if (pass == 0) p = cand; else g = cand; }
         used += taken;
     }
@@ -445,6 +448,11 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
 
     // BE:1871-1873: clip to the action space (PL:257-259)
     const RT lim = JERK ? C.j_max : C.a_max;
+    if (P.count_clipped) {  // (wave-uniform, opt-in) the reference warns before it clips, BE:1871-1873: count the env-steps it would warn about
+        const bool outside = live & (mv < M) & ((absr(a.x) > lim) | (absr(a.y) > lim));
+        const unsigned long long om = __ballot(group_any<LPE>(outside) & (mv == 0));
+        if ((om != 0ull) & (__lane_id() == 0u)) diag_add(P, 1, (uint32_t)__popcll(om));
+    }
     a.x = fmin(fmax(a.x, -lim), lim);
     a.y = fmin(fmax(a.y, -lim), lim);
 
@@ -1445,7 +1453,8 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                 GPR_WT(ct_sess += __builtin_amdgcn_s_memtime() - ct1; cn_sess += 1;)
             } else {
                 int ts = ld(&coop_best[2 * ei]), tg = ld(&coop_best[2 * ei + 1]);  // (final: see above)
-                ts = ts < max_t ? ts : max_t - 1; tg = tg < max_t ? tg : max_t - 1;  // trials exhausted: the last candidate stands
+                if (((threadIdx.x & 63) == 0) & ((ts >= max_t) | (tg >= max_t))) diag_add(P, 0, (uint32_t)(ts >= max_t) + (uint32_t)(tg >= max_t));
+                ts = ts < max_t ? ts : max_t - 1; tg = tg < max_t ? tg : max_t - 1;  // trials exhausted: the last candidate stands (counted, see group_reset)
                 GPR_WT(wt_served += 1;)
                 serve(1, GROUPS, true, renv, (entry & 1) != 0, rp, rg, true, ts, tg);
                 GPR_WT(ct_form += __builtin_amdgcn_s_memtime() - ct1;)

@@ -28,8 +28,14 @@ template <typename ST, typename RT> hipError_t launch_env_kernel_wide(bool is_re
 
 // P carries the step outputs (obs / ag / dg / reward / terminated / truncated / final_*) the views are built from
 template <typename ST> hipError_t launch_agent_views(const KParams &P, int lpe, int obs_dim, void *agent_obs, void *agent_reward, hipStream_t s);
-// sums the per-wavefront episode counters [rows][6] into totals[6] (uint64, added) and clears the rows
-hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, hipStream_t s);
+// sums the per-wavefront episode counters [rows][6] into totals[0..5] (uint64, added) and clears the rows; moves the two diagnostic
+// words diag[0..1] into totals[6..7] (and into diag[2..3], the running sums gpr_read_diagnostics reports)
+hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, uint32_t *diag, hipStream_t s);
+// get_mover_qpos / qvel / qacc (+ _arr) of every env: out [E][n_sel][7 or 6] (gpr_ops_kernels.hip)
+template <typename ST, typename RT>
+hipError_t launch_mover_state(const KParams &P, int which, int n_sel, const int32_t *sel, double z_report, int add_noise, const void *mover_rot,
+                              void *out, hipStream_t s);
+hipError_t set_normal_table_ops(const double *tab);
 
 // the double-precision normal-draw tables (gpr_device.h: g_normal_tab), one pointer instance per translation unit that draws in double
 template <typename ST, typename RT> hipError_t set_normal_table_env(const double *tab);

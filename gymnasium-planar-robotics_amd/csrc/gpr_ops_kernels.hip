@@ -223,8 +223,10 @@ template hipError_t launch_agent_views<float>(const KParams &, int, int, void *,
 template hipError_t launch_agent_views<double>(const KParams &, int, int, void *, void *, hipStream_t);
 
 // episode counters: one block sums the per-wavefront rows (a few thousand) column by column, adds to the caller's totals,
-// clears the rows. Runs on the stream of the step kernels, so it sees complete rows.
-__global__ void __launch_bounds__(BLOCK) k_counter_reduce(uint32_t *rows, int64_t n_rows, unsigned long long *totals) {
+// clears the rows. Runs on the stream of the step kernels, so it sees complete rows. The two diagnostic words (KParams::diag: reset
+// searches that ran out of trials, clipped env-steps) are MOVED into totals[6], totals[7] the same way; diag[2], diag[3] keep what was
+// moved so far, so that gpr_read_diagnostics can report totals since gpr_create whoever read in between.
+__global__ void __launch_bounds__(BLOCK) k_counter_reduce(uint32_t *rows, int64_t n_rows, unsigned long long *totals, uint32_t *diag) {
     __shared__ unsigned long long part[BLOCK / 64][6];
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t r = threadIdx.x; r < n_rows; r += BLOCK) {
@@ -242,12 +244,74 @@ __global__ void __launch_bounds__(BLOCK) k_counter_reduce(uint32_t *rows, int64_
         unsigned long long v = 0;
         for (int w = 0; w < BLOCK / 64; ++w) v += part[w][threadIdx.x];
         totals[threadIdx.x] += v;
+    } else if (threadIdx.x < 8) {
+        const int k = threadIdx.x - 6;
+        const uint32_t v = __hip_atomic_exchange(diag + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        diag[2 + k] += v;
+        totals[threadIdx.x] += v;
     }
 }
-hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, hipStream_t s) {
-    hipLaunchKernelGGL(k_counter_reduce, dim3(1), dim3(BLOCK), 0, s, rows, n_rows, reinterpret_cast<unsigned long long *>(totals));
+hipError_t launch_counter_reduce(uint32_t *rows, int64_t n_rows, uint64_t *totals, uint32_t *diag, hipStream_t s) {
+    hipLaunchKernelGGL(k_counter_reduce, dim3(1), dim3(BLOCK), 0, s, rows, n_rows, reinterpret_cast<unsigned long long *>(totals), diag);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// get_mover_qpos / get_mover_qvel / get_mover_qacc and their _arr forms (BE:801-855, 1244-1290) for every env of the handle: one thread
+// per (env, selected mover) row. which 0: qpos (x, y, z, qw, qx, qy, qz) -- z is the distance between the mover's bottom and the tile's
+// top (BE:821-824: the body's z minus the mover's half height), which the planar engine keeps at `z_report`; the quaternion is the
+// identity for the planning env and the yaw rotation (cos(yaw/2), 0, 0, sin(yaw/2)) when the handle carries the pushing env's
+// mover_rot. which 1: qvel (vx, vy, 0, 0, 0, yaw rate); which 2: qacc (ax, ay, 0, 0, 0, 0). add_noise: Gaussian noise of
+// std_noise[which] on EVERY component (BE:828, 841, 855), from the engine's counter RNG: key (seed, tick, KIND_GETTER_NOISE, env, mover),
+// components (2k, 2k+1) take normal pair k.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename ST, typename RT>
+__global__ void __launch_bounds__(BLOCK) k_mover_state(KParams P, int which, int n_sel, const int32_t *sel, RT z_report, int add_noise,
+                                                       const ST *mover_rot, ST *out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P.E * n_sel) return;
+    const int64_t e = i / n_sel;
+    const int m = sel[i - e * n_sel];
+    const Cst<RT> &C = cst<RT>(P);
+    const ST *src = static_cast<const ST *>(which == 0 ? P.pos : which == 1 ? P.vel : P.acc) + (e * P.M + m) * 2;
+    RT v[8] = {(RT)src[0], (RT)src[1], (RT)0, (RT)0, (RT)0, (RT)0, (RT)0, (RT)0};
+    const int nc = which == 0 ? 7 : 6;
+    if (which == 0) {
+        v[2] = z_report; v[3] = (RT)1;
+        if (mover_rot != nullptr) {
+            RT sn, cs;
+            Math<RT>::sincos_((RT)0.5 * (RT)mover_rot[(e * P.M + m) * 2], sn, cs);
+            v[3] = cs; v[6] = sn;
+        }
+    } else if (which == 1 && mover_rot != nullptr) {
+        v[5] = (RT)mover_rot[(e * P.M + m) * 2 + 1];
+    }
+    if (add_noise) {
+        const RT sigma = which == 0 ? C.sig_p : which == 1 ? C.sig_v : C.sig_a;
+        const uint32_t key = rng_key(P, KIND_GETTER_NOISE, P.env_id_offset + e, (uint32_t)m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const R2<RT> n = rng_normal_pair<RT>(key, (uint32_t)k);
+            v[2 * k] = v[2 * k] + sigma * n.x;
+            v[2 * k + 1] = v[2 * k + 1] + sigma * n.y;
+        }
+    }
+    ST *o = out + i * nc;
+    for (int k = 0; k < nc; ++k) o[k] = (ST)v[k];
+}
+template <typename ST, typename RT>
+hipError_t launch_mover_state(const KParams &P, int which, int n_sel, const int32_t *sel, double z_report, int add_noise, const void *mover_rot,
+                              void *out, hipStream_t s) {
+    const int64_t n = P.E * n_sel;
+    if (n > 0)
+        hipLaunchKernelGGL((k_mover_state<ST, RT>), dim3(grid_for(n)), dim3(BLOCK), 0, s, P, which, n_sel, sel, (RT)z_report, add_noise,
+                           static_cast<const ST *>(mover_rot), static_cast<ST *>(out));
+    return hipGetLastError();
+}
+template hipError_t launch_mover_state<float, float>(const KParams &, int, int, const int32_t *, double, int, const void *, void *, hipStream_t);
+template hipError_t launch_mover_state<float, double>(const KParams &, int, int, const int32_t *, double, int, const void *, void *, hipStream_t);
+template hipError_t launch_mover_state<double, double>(const KParams &, int, int, const int32_t *, double, int, const void *, void *, hipStream_t);
+hipError_t set_normal_table_ops(const double *tab) { return hipMemcpyToSymbol(HIP_SYMBOL(g_normal_tab), &tab, sizeof(tab)); }
 
 hipError_t launch_segments(int64_t n, const double *p1, const double *p2, const double *q1, const double *q2, uint8_t *out, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_segments, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, p1, p2, q1, q2, out);

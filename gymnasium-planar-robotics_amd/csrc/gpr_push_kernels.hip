@@ -585,6 +585,9 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
             }
             if constexpr (NM == 1) break;
         }
+        if constexpr (NM > 1) {  // trials exhausted: the last (overlapping) pair of starts stands -- counted (GPR_CNT_RESET_EXHAUSTED)
+            if (pending & need & lead) diag_add(P, 0, 1u);
+        }
     }
     // PU:396-407: object start by rejection, strict distance rule to every mover. Where a mover starts near the centre of the 3x3
     // tiles almost no object position qualifies (the reference then loops for thousands of trials, at the very centre forever), so
@@ -626,13 +629,17 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
 #pragma unroll
         for (int i = 0; i < NM; ++i) { mp[i].x = lane_bcast<RT>(p[i].x, L); mp[i].y = lane_bcast<RT>(p[i].y, L); }
         int found = max_trials - 1;
+        bool exhausted = true;
         for (int base = NSELF; base < max_trials; base += 64) {
             const int trial = base + (int)__lane_id();
             RT cx, cy;
             candidate(ksL, eL, trial, cx, cy);
             const unsigned long long okm = __ballot((trial < max_trials) & far_enough(cx, cy, mp));
-            if (okm != 0ull) { found = base + __builtin_ctzll(okm); break; }
+            if (okm != 0ull) { found = base + __builtin_ctzll(okm); exhausted = false; break; }
         }
+        // PU:396-402: the reference goes on looping and warns every 100 trials; here the last candidate stands although it is too close to
+        // a mover -- counted (GPR_CNT_RESET_EXHAUSTED; not for a caller-supplied candidate stream, whose last set stands by contract)
+        if (exhausted & (X.cand == nullptr) & ((int)__lane_id() == L)) diag_add(P, 0, 1u);
         RT cx, cy;
         candidate(ksL, eL, found, cx, cy);
         if (((int)__lane_id() >> gsh) == (L >> gsh)) { ox = cx; oy = cy; n_tried = found + 1; }  // the env's whole group takes the result
@@ -710,12 +717,18 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
         R2<RT> a[NM];
         const RT lim = JERK ? C.j_max : C.a_max;
         uint32_t key[NM];
+        bool outside = false;  // BE:1871-1873: the reference warns before it clips (counted when the caller asked for it, see below)
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             a[i] = load2<ST, RT>(P.action, 2 * NM * e + 2 * i);
+            outside |= (absr(a[i].x) > lim) | (absr(a[i].y) > lim);
             a[i].x = fmin(fmax(a[i].x, -lim), lim);
             a[i].y = fmin(fmax(a[i].y, -lim), lim);
             key[i] = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)i);
+        }
+        if (P.count_clipped) {  // (wave-uniform, opt-in)
+            const unsigned long long om = __ballot(outside & live);
+            if ((om != 0ull) & (__lane_id() == 0u)) diag_add(P, 1, (uint32_t)__popcll(om));
         }
         reset_first = (P.autoreset == 2) & (el < 0);
         const CircleSize<RT> cw_step = circle_size<RT>(P, (c + C.c_offset_wall) + (RT)0 * C.c_offset);

@@ -1,7 +1,7 @@
 """Multi-GPU plumbing: env batches shard embarrassingly (the reference is literally one env per process): ``step()`` and
 ``reset()`` exchange nothing. What a rollout flush moves is the caller's choice:
 
-* nothing but the six episode counters (``env.all_reduce_episode_counters()``: ONE 48-byte all_reduce) when every rank's learner
+* nothing but the eight episode counters (``env.all_reduce_episode_counters()``: ONE 64-byte all_reduce) when every rank's learner
   consumes its own ``RolloutBuffer`` shard -- the default of ``bench.py``; at this engine's step rate a rank produces
   ~134 B x 3.7e9 env-steps/s = 500 GB/s of rollout data, more than the xGMI links of a GPU can take in from seven peers;
 * a learner-sized minibatch (``RolloutBuffer.gather_minibatch``): ONE all-gather of [T, n, .] slices of the fields a learner reads;

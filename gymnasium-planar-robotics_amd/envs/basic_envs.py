@@ -237,6 +237,10 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
 
     def close(self, **kwargs) -> None:
         if getattr(self, '_handle', None) is not None:
+            try:
+                self.warn_diagnostics()  # what the reference would have printed while it ran (reset searches without a valid sample, clipped actions)
+            except Exception:
+                pass
             self._lib.gpr_destroy(self._handle)
             self._handle = None
         self.closed = True
@@ -306,15 +310,16 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
         self._counters_on = bool(enable)
 
     def read_episode_counters(self) -> torch.Tensor:
-        """int64 device tensor [6] = running totals in the order of ``_native.COUNTERS`` (episodes, terminated, truncated, success,
-        wall_collision, mover_collision) since ``enable_episode_counters``. One tiny reduce kernel, no host sync."""
+        """int64 device tensor [8] = running totals in the order of ``_native.COUNTERS`` (episodes, terminated, truncated, success,
+        wall_collision, mover_collision, reset_exhausted, actions_clipped) since ``enable_episode_counters``. One tiny reduce kernel, no
+        host sync."""
         assert getattr(self, '_counters_on', False), 'call enable_episode_counters() first'
         with torch.cuda.device(self.device):
             _native.check(self._lib.gpr_read_counters(self._handle, self._counter_totals.data_ptr(), self._stream()), self._handle)
         return self._counter_totals
 
     def all_reduce_episode_counters(self) -> torch.Tensor:
-        """Job-wide totals: ONE all_reduce (SUM) of the six counters over the default process group -- the only collective a
+        """Job-wide totals: ONE all_reduce (SUM) of the eight counters over the default process group -- the only collective a
         rollout flush needs when every rank's learner consumes its own shard."""
         import torch.distributed as dist
         if not getattr(self, '_counters_on', False):
@@ -328,6 +333,78 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
             else:
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         return tot
+
+    # ------------------------------------------------------------------------------------------------------------
+    # the reference's warnings, batched: counted on the device, reported on the host
+    # ------------------------------------------------------------------------------------------------------------
+    def count_clipped_actions(self, enable: bool = True) -> None:
+        """Let the step kernels count the env-steps whose action lies outside the action space. The reference prints 'action is not within
+        the action space' and clips (BE:1871-1873); the engine always clips, and -- after this call -- counts, so that
+        ``diagnostics()`` / ``warn_diagnostics()`` can say how often."""
+        _native.check(self._lib.gpr_count_clipped_actions(self._handle, int(enable)), self._handle)
+
+    def diagnostics(self) -> dict[str, int]:
+        """{'reset_exhausted': rejection searches of resets (starts, goals, the pushing env's object) that used up ``max_reset_trials`` -- the
+        last candidate then stands although it is INVALID; 'actions_clipped': env-steps with an out-of-range action (after
+        ``count_clipped_actions()``)} since the env was created. Waits for the env's stream (a diagnostic read)."""
+        tot = (C.c_uint64 * 2)()
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.gpr_read_diagnostics(self._handle, tot, self._stream()), self._handle)
+        return {'reset_exhausted': int(tot[0]), 'actions_clipped': int(tot[1])}
+
+    def warn_diagnostics(self) -> dict[str, int]:
+        """``diagnostics()``, and a ``warnings.warn`` for every count that grew since the last call: what the reference logs while it runs
+        (PL:371-375, 397-401, PU:398-402: 'Trying to find a start / goal configuration ...'; BE:1871-1873). Called by ``reset()`` and
+        ``close()``; call it from a training loop's logging step to hear about auto-resets in time."""
+        d = self.diagnostics()
+        seen = getattr(self, '_diag_seen', {'reset_exhausted': 0, 'actions_clipped': 0})
+        if d['reset_exhausted'] > seen['reset_exhausted']:
+            warnings.warn(f"{d['reset_exhausted'] - seen['reset_exhausted']} reset search(es) found no valid start / goal configuration within "
+                          f"max_reset_trials = {getattr(self, 'max_reset_trials', '?')} trials: the last (invalid) sample was kept. Consider choosing "
+                          'more tiles or fewer movers (the reference loops on and warns every 100 trials).')
+        if d['actions_clipped'] > seen['actions_clipped']:
+            warnings.warn(f"{d['actions_clipped'] - seen['actions_clipped']} env-step(s) had an action outside the action space; it was clipped "
+                          '(BE:1871-1873).')
+        self._diag_seen = d
+        return d
+
+    # ------------------------------------------------------------------------------------------------------------
+    # noisy state getters (BE:801-855, 1244-1290), batched over the envs
+    # ------------------------------------------------------------------------------------------------------------
+    def _mover_state(self, which: int, mover_names, add_noise: bool) -> torch.Tensor:
+        idx = [self.mover_names.index(n) for n in mover_names]  # (a name that is no mover raises ValueError, like BE:813)
+        sel = torch.tensor(idx, dtype=torch.int32, device=self.device)
+        out = torch.empty(self.num_envs, len(idx), 7 if which == 0 else 6, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.gpr_get_mover_state(self._handle, which, len(idx), sel.data_ptr(), float(self.initial_mover_zpos), int(add_noise),
+                                                        out.data_ptr(), self._stream()), self._handle)
+        return out
+
+    def get_mover_qpos(self, mover_name: str, add_noise: bool = False) -> torch.Tensor:
+        """``get_mover_qpos`` (BE:801-828) of every env: ``[num_envs, 7]`` = (x_p, y_p, z_p, w_o, x_o, y_o, z_o). As in the reference, z is
+        the distance between the bottom of the mover and the top of a tile (BE:821-824) -- ``initial_mover_zpos`` throughout: the engine's
+        movers are planar. ``add_noise``: Gaussian noise of ``std_noise[0]`` on every component."""
+        return self._mover_state(0, [mover_name], add_noise)[:, 0]
+
+    def get_mover_qvel(self, mover_name: str, add_noise: bool = False) -> torch.Tensor:
+        """``get_mover_qvel`` (BE:830-841): ``[num_envs, 6]`` = (x, y, z, a, b, c) velocities; noise ``std_noise[1]``."""
+        return self._mover_state(1, [mover_name], add_noise)[:, 0]
+
+    def get_mover_qacc(self, mover_name: str, add_noise: bool = False) -> torch.Tensor:
+        """``get_mover_qacc`` (BE:843-855): ``[num_envs, 6]`` accelerations; noise ``std_noise[2]``."""
+        return self._mover_state(2, [mover_name], add_noise)[:, 0]
+
+    def get_mover_qpos_arr(self, mover_names: list[str], add_noise: bool = False) -> torch.Tensor:
+        """``get_mover_qpos_arr`` (BE:1244-1258): ``[num_envs, len(mover_names), 7]``, rows in the order of the names."""
+        return self._mover_state(0, mover_names, add_noise)
+
+    def get_mover_qvel_arr(self, mover_names: list[str], add_noise: bool = False) -> torch.Tensor:
+        """``get_mover_qvel_arr`` (BE:1260-1274): ``[num_envs, len(mover_names), 6]``."""
+        return self._mover_state(1, mover_names, add_noise)
+
+    def get_mover_qacc_arr(self, mover_names: list[str], add_noise: bool = False) -> torch.Tensor:
+        """``get_mover_qacc_arr`` (BE:1276-1290): ``[num_envs, len(mover_names), 6]``."""
+        return self._mover_state(2, mover_names, add_noise)
 
     def _preprocess_info(self, info) -> tuple[torch.Tensor, torch.Tensor, bool]:
         """``_preprocess_info_dict`` (PL:666-688, PU:670-689): the collision flags of a batch as uint8 device tensors. Accepts what the

@@ -66,6 +66,7 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         env_id_offset: int = 0,
         max_reset_trials: int = 10000,
         num_movers: int = 1,
+        warn_on_reset: bool = True,
         _host_only: bool = False,
         _push_overrides: dict[str, float] | None = None,
     ) -> None:
@@ -87,6 +88,7 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
         self.v_max, self.a_max, self.j_max, self.threshold_pos = float(v_max), float(a_max), float(j_max), float(threshold_pos)
         self.max_episode_steps, self.autoreset_mode, self.precision = max_episode_steps, autoreset_mode, precision
         self.env_id_offset, self.dtype = int(env_id_offset), _TORCH_DTYPE[precision]
+        self.warn_on_reset, self.max_reset_trials = bool(warn_on_reset), int(max_reset_trials)
         self.metadata = dict(self.metadata, autoreset_mode=spaces.autoreset_metadata(autoreset_mode))
 
         # spaces (PU:232-253)
@@ -201,6 +203,8 @@ class VecBenchmarkPushingEnv(VecBasicPlanarRoboticsEnv):
                                                         start.data_ptr() if start is not None else None,
                                                         goal.data_ptr() if goal is not None else None, C.byref(self._out), self._stream()),
                           self._handle)
+        if self.warn_on_reset:
+            self.warn_diagnostics()  # PU:398-402: an object search that found no valid sample is reported (one host synchronisation)
         return OrderedDict(self._obs), self._info_dict()
 
     def step(self, action: torch.Tensor):

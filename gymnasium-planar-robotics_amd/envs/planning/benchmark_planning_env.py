@@ -47,6 +47,10 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
     :param env_id_offset: global index of local env 0; random streams are keyed by global index, so a sharded run reproduces
         the single-device run
     :param alias_desired_goal: return the goal state tensor itself as ``desired_goal`` (no copy per step)
+    :param max_reset_trials: bound of the rejection loops of a reset (the reference has none: PL:369, 395 loop until a sample is valid and
+        warn every 100 trials); a search that runs into it keeps its last, invalid sample and is COUNTED (``diagnostics()``)
+    :param warn_on_reset: ``reset()`` ends with ``warn_diagnostics()`` -- one host synchronisation per explicit reset -- so that such
+        searches (also those of the auto-resets since the last call) are reported the way the reference reports them
     """
 
     reward_success = 50  # PL:220
@@ -80,6 +84,7 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         env_id_offset: int = 0,
         max_reset_trials: int = 10000,
         alias_desired_goal: bool = False,
+        warn_on_reset: bool = True,
         _host_only: bool = False,
     ) -> None:
         if show_2D_plot and mover_colors_2D_plot is None:
@@ -100,6 +105,8 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         self.autoreset_mode = autoreset_mode
         self.precision = precision
         self.env_id_offset = int(env_id_offset)
+        self.warn_on_reset = bool(warn_on_reset)
+        self.max_reset_trials = int(max_reset_trials)
         self.dtype = _TORCH_DTYPE[precision]
         self.metadata = dict(self.metadata, autoreset_mode=spaces.autoreset_metadata(autoreset_mode))
 
@@ -205,6 +212,8 @@ class VecBenchmarkPlanningEnv(VecBasicPlanarRoboticsEnv):
         with torch.cuda.device(self.device):
             _native.check(self._lib.gpr_reset(self._handle, mask.data_ptr() if mask is not None else None, C.byref(self._out),
                                               self._stream()), self._handle)
+        if self.warn_on_reset:
+            self.warn_diagnostics()  # PL:371-375, 397-401: a search that found no valid sample is reported (one host synchronisation)
         return self._obs_dict(), self._info_dict()
 
     def step(self, action: torch.Tensor) -> tuple[OrderedDict, torch.Tensor, torch.Tensor, torch.Tensor, dict[str, torch.Tensor]]:

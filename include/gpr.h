@@ -151,8 +151,9 @@ int gpr_step_n(gpr_env *env, int32_t n_steps, const void *action_dev, const gpr_
 
 /* Episode counters (engine addition, SURVEY.md section 5: the reference logs nothing). Every step kernel adds, per wavefront,
  * the popcounts of its done masks to a small device table owned by the handle; gpr_read_counters sums that table into the
- * caller's six uint64 totals (added to what is there), and clears the table. Counting starts with the first
- * gpr_enable_counters(env, 1); while disabled the step kernels do not touch the table. */
+ * caller's uint64 totals (added to what is there), and clears the table. Counting starts with the first
+ * gpr_enable_counters(env, 1); while disabled the step kernels do not touch the table. Totals 6 and 7 are the two diagnostics the
+ * reference prints as warnings (they are counted whether or not the episode counters are enabled, see gpr_read_diagnostics). */
 enum {
     GPR_CNT_EPISODES = 0,     /* env-steps with terminated | truncated */
     GPR_CNT_TERMINATED = 1,   /* PL:459-479 */
@@ -160,10 +161,31 @@ enum {
     GPR_CNT_SUCCESS = 3,      /* info['is_success'] */
     GPR_CNT_WALL = 4,         /* info['wall_collision'] */
     GPR_CNT_PAIR = 5,         /* info['mover_collision'] */
-    GPR_NUM_COUNTERS = 6
+    GPR_CNT_RESET_EXHAUSTED = 6, /* rejection searches of a reset (starts, goals, the pushing env's object) that used up max_reset_trials:
+                                    the last candidate stands although it is INVALID. The reference never gives up and warns every 100
+                                    trials (PL:371-375, 397-401, PU:398-402); the host layer warns when this count is non-zero */
+    GPR_CNT_ACTIONS_CLIPPED = 7, /* env-steps whose action lay outside the action space and was clipped (the reference warns, BE:1871-1873);
+                                    counted only after gpr_count_clipped_actions(env, 1) */
+    GPR_NUM_COUNTERS = 8
 };
 int gpr_enable_counters(gpr_env *env, int32_t enable);
 int gpr_read_counters(gpr_env *env, uint64_t *totals_dev /* [GPR_NUM_COUNTERS], device, caller-owned */, void *hip_stream);
+/* opt-in: let the step kernels count the env-steps the reference would print "action is not within the action space" for (BE:1871-1873) */
+int gpr_count_clipped_actions(gpr_env *env, int32_t enable);
+/* The two diagnostics since gpr_create as HOST values: totals_host[0] = GPR_CNT_RESET_EXHAUSTED, [1] = GPR_CNT_ACTIONS_CLIPPED. Waits for
+ * hip_stream (a diagnostic read, not a hot-path call); independent of gpr_enable_counters / gpr_read_counters. */
+int gpr_read_diagnostics(gpr_env *env, uint64_t *totals_host /* [2] */, void *hip_stream);
+
+/* get_mover_qpos / get_mover_qvel / get_mover_qacc and get_mover_qpos_arr / _qvel_arr / _qacc_arr (BE:801-855, 1244-1290) for every env
+ * of the handle. which: 0 qpos -> out [E][n_sel][7] = (x, y, z, qw, qx, qy, qz); 1 qvel -> [E][n_sel][6] = (vx, vy, vz, wa, wb, wc);
+ * 2 qacc -> [E][n_sel][6]. mover_idx_dev [n_sel] int32: row j of an env is mover mover_idx[j] (the order of the reference's mover_names
+ * argument). z is what the reference reports, the distance between the mover's bottom and the tile's top (BE:821-824: body z minus the
+ * half height) -- constant in this planar engine, passed by the caller (initial_mover_zpos); the quaternion is the identity (planning
+ * env) or the yaw rotation (pushing env); z / roll / pitch rates and accelerations are 0. add_noise: Gaussian noise of std_noise[which]
+ * on EVERY component, as BE:828 / 841 / 855 add it, from random stream kind 5 of gpr-rng-v1 (key (seed, call counter, 5, global env id,
+ * mover), components 2k and 2k+1 = normal pair k); a noisy read advances the call counter. Real type = the handle's storage type. */
+int gpr_get_mover_state(gpr_env *env, int32_t which, int32_t n_sel, const int32_t *mover_idx_dev, double z_report, int32_t add_noise,
+                        void *out_dev, void *hip_stream);
 /* compute_reward / compute_terminated on HER batches (PL:459-534): achieved/desired [batch][2M] real. */
 int gpr_compute_reward(gpr_env *env, int64_t batch, const void *achieved_dev, const void *desired_dev,
                        const uint8_t *mover_collision_dev, const uint8_t *wall_collision_dev, void *reward_dev,

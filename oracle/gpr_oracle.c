@@ -490,7 +490,39 @@ void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1) {
     *n1 = rad * sin(ang);
 }
 
-enum { KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4 };
+enum { KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4, KIND_GETTER_NOISE = 5 };
+
+/* get_mover_qpos / qvel / qacc and the _arr forms (BE:801-855, 1244-1290) of every env, in the batched engine's terms (include/gpr.h,
+ * gpr_get_mover_state): BE:821-824 reports z as the body's z minus the mover's half height = the gap above the tile, constant here
+ * (z_report); BE:828 / 841 / 855 add N(0, std_noise[which] * int(add_noise)) to EVERY component. */
+void gpro_get_mover_state(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset, int32_t which,
+                          int32_t n_sel, const int32_t *mover_idx, double z_report, int32_t add_noise, const double *pos, const double *vel,
+                          const double *acc, const double *mover_rot, double *out) {
+    const int M = cfg->num_movers, nc = which == 0 ? 7 : 6;
+    const double sigma = cfg->std_noise[which];
+    for (int64_t e = 0; e < num_envs; ++e)
+        for (int j = 0; j < n_sel; ++j) {
+            const int m = mover_idx[j];
+            const double *src = (which == 0 ? pos : which == 1 ? vel : acc) + (e * M + m) * 2;
+            double v[8] = {src[0], src[1], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (which == 0) {
+                v[2] = z_report; v[3] = 1.0;
+                if (mover_rot) { v[3] = cos(0.5 * mover_rot[(e * M + m) * 2]); v[6] = sin(0.5 * mover_rot[(e * M + m) * 2]); }
+            } else if (which == 1 && mover_rot) {
+                v[5] = mover_rot[(e * M + m) * 2 + 1];
+            }
+            if (add_noise) {
+                const uint32_t key = gpro_rng_key(seed, tick, KIND_GETTER_NOISE, (uint64_t)(env_id_offset + e), (uint32_t)m);
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    double n0, n1;
+                    gpro_rng_normal_pair(key, k, &n0, &n1);
+                    v[2 * k] = v[2 * k] + sigma * n0;
+                    v[2 * k + 1] = v[2 * k + 1] + sigma * n1;
+                }
+            }
+            for (int k = 0; k < nc; ++k) out[(e * n_sel + j) * nc + k] = cfg->storage_f32 ? (double)(float)v[k] : v[k];
+        }
+}
 
 /* ======================================================================================================
  * Vectorised BenchmarkPlanningEnv (BE:1770-1950 template + PL callbacks), one env at a time.

@@ -101,6 +101,12 @@ uint32_t gpro_rng_draw(uint32_t key, uint32_t k);
 double gpro_rng_uniform(uint32_t key, uint32_t k);
 void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1);
 
+/* get_mover_qpos / qvel / qacc (+ _arr) of every env (BE:801-855, 1244-1290): which 0 qpos -> out [E][n_sel][7], 1 qvel / 2 qacc -> [E][n_sel][6].
+ * mover_rot nullable [E][2M] (yaw, yaw rate: the pushing env). Noise: stream kind 5 of gpr-rng-v1, components (2k, 2k+1) = normal pair k. */
+void gpro_get_mover_state(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset, int32_t which,
+                          int32_t n_sel, const int32_t *mover_idx, double z_report, int32_t add_noise, const double *pos, const double *vel,
+                          const double *acc, const double *mover_rot, double *out);
+
 /* ---- vectorised env -------------------------------------------------------------------------------------- */
 /* State layout (oracle side): [E][2M] row-major doubles for pos/vel/acc/goal, elapsed [E] int32.
  * autoreset: 0 = disabled, 1 = same-step (done envs are re-sampled inside the call and the returned observation is

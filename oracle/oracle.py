@@ -260,6 +260,19 @@ class OraclePlanningEnv:
         self.tick += 1
         return self._result(), n_used
 
+    def get_mover_state(self, which, mover_idx, z_report, add_noise=False, mover_rot=None):
+        """get_mover_qpos / qvel / qacc (+ _arr) of every env (BE:801-855, 1244-1290): which 0 / 1 / 2 -> [E, n_sel, 7 / 6 / 6]; a noisy read
+        consumes one call-counter tick like the engine's"""
+        idx = np.ascontiguousarray(mover_idx, dtype=np.int32)
+        out = np.zeros((self.E, len(idx), 7 if which == 0 else 6))
+        rot = None if mover_rot is None else _f64(mover_rot)
+        lib().gpro_get_mover_state(C.byref(self.cfg), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick), C.c_int64(self.env_id_offset),
+                                   C.c_int32(which), C.c_int32(len(idx)), _p(idx), C.c_double(z_report), C.c_int32(int(add_noise)), _p(self.pos),
+                                   _p(self.vel), _p(self.acc), _p(rot), _p(out))
+        if add_noise:
+            self.tick += 1
+        return out
+
     def step(self, action):
         a = _f64(action).reshape(self.E, 2 * self.M)
         args = [C.byref(self.cfg), C.c_int64(self.E), C.c_uint64(self.seed), C.c_uint64(self.tick), C.c_int64(self.env_id_offset), _p(a),

@@ -35,6 +35,9 @@ known-answer cases the reference's own tests hold):
   pushing_methods.npz            BenchmarkPushingEnv._get_obs (PU:529-576), compute_reward / compute_terminated (PU:457-527) on arrays of info
                                  dicts, _reset_callback (PU:373-417) incl. the `options`, with scripted np_random.uniform -- as written (a16)
 
+  getters.npz                    get_mover_qpos / get_mover_qvel / get_mover_qacc and the _arr forms (BE:801-855, 1244-1290) as written on the
+                                 stand-in world: z convention, row order, and the additive noise on every component (unit normals scripted)
+
 MuJoCo itself is not installed, so nothing here depends on mj_step (see _import_reference.py).
 """
 from __future__ import annotations
@@ -985,7 +988,73 @@ def gen_pushing_methods(seed=71):
     np.savez_compressed(os.path.join(HERE, 'pushing_methods.npz'), **out)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 12. the public state getters as written (round 4): get_mover_qpos / qvel / qacc and the _arr forms (BE:801-855, 1244-1290)
+# ----------------------------------------------------------------------------------------------------------
+class ScriptedNormal:
+    """rng_noise stand-in: normal(loc, scale, size) = loc + scale * the next `size` prescribed unit normals (records every call)"""
+
+    def __init__(self, units):
+        self.units, self.k, self.calls = np.asarray(units, dtype=np.float64).reshape(-1), 0, []
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        n = int(np.prod(size)) if size is not None else 1
+        u = self.units[self.k:self.k + n]
+        self.k += n
+        self.calls.append((float(scale), n))
+        return loc + scale * u.reshape(size if size is not None else ())
+
+
+def gen_getters(seed=81):
+    """The reference's getters called as written on the stand-in world: the z convention (body z minus the mover's half height, box index 2 /
+    cylinder index 1, BE:821-824), the row order of the _arr forms (= the order of the names passed), and what add_noise adds (std_noise[0] /
+    [1] / [2] times a unit normal on EVERY component of qpos / qvel / qacc, BE:828, 841, 855) -- the unit normals are scripted."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    cases = [('box4', dict(num_movers=4), None), ('box3_sizes', dict(num_movers=3, mover_params={'size': np.array([[0.07, 0.07, 0.006], [0.05, 0.06, 0.004], [0.0775, 0.0775, 0.01]])}), None),
+             ('cyl2', dict(num_movers=2, mover_params={'shape': 'cylinder', 'size': np.array([0.07, 0.005, 0.001])}), None)]
+    for tag, kw, _ in cases:
+        env = planning_env(layout_tiles=np.ones((4, 4)), std_noise=np.array([1e-3, 2e-3, 3e-3]), **kw)
+        M = env.num_movers
+        world = World(env, False).install()
+        try:
+            xy = rng.uniform(0.2, 0.7, size=(M, 2))
+            world.load(xy)
+            if env.mover_shape == 'cylinder':  # (World.load puts box movers at their body height; a cylinder's height is size[1], BE:1070)
+                world.qpos[:, 2] = env.initial_mover_zpos + env.mover_size[:, 1]
+            world.qvel[:, :2] = rng.uniform(-1, 1, size=(M, 2)); world.qacc[:, :2] = rng.uniform(-5, 5, size=(M, 2))
+            order = list(rng.permutation(M))
+            names = [env.mover_names[i] for i in order]
+            res = {}
+            for which, fn_arr, fn_one, nc in ((0, env.get_mover_qpos_arr, env.get_mover_qpos, 7), (1, env.get_mover_qvel_arr, env.get_mover_qvel, 6),
+                                              (2, env.get_mover_qacc_arr, env.get_mover_qacc, 6)):
+                env.rng_noise = ScriptedNormal(np.zeros(1000))
+                clean = fn_arr(names, add_noise=False)
+                units = rng.standard_normal((M, nc))
+                env.rng_noise = sn = ScriptedNormal(units)
+                noisy = fn_arr(names, add_noise=True)
+                assert all(c == (float(env.std_noise[which]), nc) for c in sn.calls) and len(sn.calls) == M
+                env.rng_noise = ScriptedNormal(np.zeros(16))
+                one = fn_one(env.mover_names[order[0]], add_noise=False)
+                assert np.array_equal(one, clean[0])
+                res[which] = (clean, noisy, units)
+            out[f'{tag}_M'] = np.array(M); out[f'{tag}_order'] = np.array(order)
+            out[f'{tag}_initial_mover_zpos'] = np.array(env.initial_mover_zpos); out[f'{tag}_std_noise'] = env.std_noise.copy()
+            out[f'{tag}_pos'] = world.qpos[:, :2].copy(); out[f'{tag}_vel'] = world.qvel[:, :2].copy(); out[f'{tag}_acc'] = world.qacc[:, :2].copy()
+            out[f'{tag}_mover_size'] = env.mover_size.copy()
+            for which, nm in ((0, 'qpos'), (1, 'qvel'), (2, 'qacc')):
+                out[f'{tag}_{nm}'] = res[which][0]; out[f'{tag}_{nm}_noisy'] = res[which][1]; out[f'{tag}_{nm}_units'] = res[which][2]
+        finally:
+            world.uninstall()
+    out['tags'] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, 'getters.npz'), **out)
+    print('getters:', ', '.join(f'{c[0]}' for c in cases))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'round4':  # only the fixture added in round 4
+        gen_getters()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'round3':  # only the fixtures added in round 3
         gen_step_template()
         gen_reset_template()
@@ -1009,3 +1078,4 @@ if __name__ == '__main__':
     gen_step_template()
     gen_reset_template()
     gen_pushing_methods()
+    gen_getters()

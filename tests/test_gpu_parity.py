@@ -675,10 +675,11 @@ def test_episode_counters_match_the_flags(gpr, M, n, E):
         want += np.array([int((term | trunc).sum()), int(term.sum()), int(trunc.sum()), int(info['is_success'].sum()),
                           int(info['wall_collision'].sum()), int(info['mover_collision'].sum())])
         if t == 30:
-            assert np.array_equal(env.read_episode_counters().cpu().numpy(), want)  # totals accumulate across reads
-    assert np.array_equal(env.read_episode_counters().cpu().numpy(), want)
+            assert np.array_equal(env.read_episode_counters().cpu().numpy()[:6], want)  # totals accumulate across reads
+    tot = env.read_episode_counters().cpu().numpy()
+    assert np.array_equal(tot[:6], want) and tot[6] == 0 and tot[7] == 0  # (no search exhausted; clipped actions are not being counted)
     assert want[0] > E and want[2] > 0 and want[4] > 0
-    assert np.array_equal(env.all_reduce_episode_counters().cpu().numpy(), want)  # single process: the same numbers
+    assert np.array_equal(env.all_reduce_episode_counters().cpu().numpy()[:6], want)  # single process: the same numbers
     env.close()
 
 
@@ -1047,3 +1048,99 @@ def test_reset_template_matches_reference_reset(gpr, oracle, precision):
     assert np.allclose(env.pos.double().cpu().numpy()[0], bad.reshape(-1), atol=1e-6) and np.allclose(env.goals.double().cpu().numpy()[0], bad.reshape(-1), atol=1e-6)
     assert got_used.tolist() == [3, 3, 2], got_used
     env.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 4: the public state getters (BE:801-855, 1244-1290) and the reference's warnings as device counts
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('precision', ['f64', 'f32'])
+def test_state_getters_match_the_reference_getters(gpr, oracle, precision):
+    """get_mover_qpos / qvel / qacc (+ _arr) against getters.npz -- the reference's getters called as written on the stand-in world: the z
+    convention (body z minus half height = the gap above the tile, BE:821-824), row order = order of the names, noise on EVERY component
+    with std_noise[0] / [1] / [2]; the noisy read bit for bit against the oracle's statement of the engine's stream (f64)."""
+    z = load_npz('getters.npz')
+    tol = 1e-15 if precision == 'f64' else 1e-6
+    for tag in z['tags']:
+        M, order = int(z[f'{tag}_M']), [int(i) for i in z[f'{tag}_order']]
+        sn = z[f'{tag}_std_noise']
+        mp = {'size': z[f'{tag}_mover_size'][0] if tag.startswith('cyl') else z[f'{tag}_mover_size']}
+        if tag.startswith('cyl'):
+            mp['shape'] = 'cylinder'
+        E = 64
+        env = gpr.VecBenchmarkPlanningEnv(np.ones((4, 4)), M, num_envs=E, precision=precision, std_noise=sn, mover_params=mp,
+                                          initial_mover_zpos=float(z[f'{tag}_initial_mover_zpos']), autoreset_mode='disabled')
+        env.reset(seed=4)
+        for k, t in (('pos', env.pos), ('vel', env.vel), ('acc', env.acc)):
+            t.copy_(torch.as_tensor(z[f'{tag}_{k}'].reshape(1, 2 * M), dtype=env.dtype).expand(E, 2 * M))
+        names = [env.mover_names[i] for i in order]
+        for which, nm, nc in ((0, 'qpos', 7), (1, 'qvel', 6), (2, 'qacc', 6)):
+            arr = getattr(env, f'get_mover_{nm}_arr')(names)
+            assert arr.shape == (E, M, nc) and arr.dtype == env.dtype
+            assert np.abs(arr.double().cpu().numpy() - z[f'{tag}_{nm}'][None]).max() <= tol, (tag, nm)
+            one = getattr(env, f'get_mover_{nm}')(names[1 % M])
+            assert torch.equal(one, arr[:, 1 % M])
+            # noise: every component, sigma = std_noise[which] (the reference: clean + std_noise[which] * unit normal, all components)
+            assert np.allclose(z[f'{tag}_{nm}_noisy'] - z[f'{tag}_{nm}'], sn[which] * z[f'{tag}_{nm}_units'], atol=1e-15)
+            big = gpr.VecBenchmarkPlanningEnv(np.ones((4, 4)), M, num_envs=8192, precision=precision, std_noise=sn, autoreset_mode='disabled')
+            big.reset(seed=1)
+            d = (getattr(big, f'get_mover_{nm}_arr')(big.mover_names, add_noise=True) - getattr(big, f'get_mover_{nm}_arr')(big.mover_names)).double()
+            sd = d.reshape(-1, nc).std(dim=0).cpu().numpy()
+            assert np.all(np.abs(sd / sn[which] - 1.0) < 0.03), (tag, nm, sd)
+            assert abs(float(d.mean())) < 0.02 * sn[which]
+            big.close()
+        if precision == 'f64':  # the engine's noise stream, bit for bit (kind 5 of gpr-rng-v1)
+            o = oracle.OraclePlanningEnv(np.ones((4, 4)), M, E, std_noise=sn)
+            o.pos[:], o.vel[:], o.acc[:] = env.pos.cpu().numpy(), env.vel.cpu().numpy(), env.acc.cpu().numpy()
+            o.seed, o.tick = env.get_rng_state()
+            for which, nm in ((0, 'qpos'), (1, 'qvel'), (2, 'qacc')):
+                want = o.get_mover_state(which, order, env.initial_mover_zpos, add_noise=True)
+                got = getattr(env, f'get_mover_{nm}_arr')(names, add_noise=True).cpu().numpy()
+                assert np.abs(got - want).max() < 1e-15, (tag, nm)
+            assert env.get_rng_state() == (o.seed, o.tick), 'a noisy read advances the call counter by one'
+        with pytest.raises(ValueError):
+            env.get_mover_qpos('mover_99')
+        env.close()
+
+
+def test_exhausted_reset_searches_and_clipped_actions_are_counted(gpr, oracle):
+    """The reference never gives up a reset search and warns every 100 trials (PL:371-375, 397-401); it warns about an action outside the
+    action space before clipping it (BE:1871-1873). The engine bounds the search and clips silently on the device -- and COUNTS both:
+    diagnostics(), counters 6 / 7, and a host warning from reset() / warn_diagnostics() / close()."""
+    import warnings
+    # 12 movers of radius 0.11 on 7 x 7 tiles need hundreds of trials: with max_reset_trials = 3 nearly every search is exhausted
+    E, M = 512, 12
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((7, 7)), M, num_envs=E, max_reset_trials=3, precision='f64')
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        env.reset(seed=0)
+    assert any('found no valid start / goal configuration' in str(x.message) for x in w), [str(x.message) for x in w]
+    d = env.diagnostics()
+    o = oracle.OraclePlanningEnv(np.ones((7, 7)), M, E, max_reset_trials=3)
+    o.reset(seed=0)
+    # an exhausted search leaves an invalid set: every env whose start set collides (safety offsets, noise-free) had its start search exhausted
+    q = np.zeros((E * M, 7)); q[:, :2] = env.pos.cpu().numpy().reshape(-1, 2); q[:, 3] = 1.0
+    bad_wall = ~env.qpos_is_valid(q, 0.11, add_safety_offset=True).bool().cpu().numpy().reshape(E, M).all(axis=1)
+    bad_pair = env.check_mover_collision(q.reshape(E, M, 7), 0.11, add_safety_offset=True).cpu().numpy()
+    n_bad_start = int((bad_wall | bad_pair).sum())
+    assert n_bad_start > E // 2 and d['reset_exhausted'] >= n_bad_start, (d, n_bad_start)
+    assert d['reset_exhausted'] <= 2 * E and d['actions_clipped'] == 0
+    # a generous bound: nothing is exhausted, nothing is reported
+    ok = gpr.VecBenchmarkPlanningEnv(np.ones((6, 6)), 4, num_envs=4096)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ok.reset(seed=0)
+        ok.count_clipped_actions()
+        a = torch.zeros(4096, 8, device='cuda')
+        a[:100, 3] = 10.5; a[50:200, 6] = -11.0; a[300, 0] = 10.0  # (exactly a_max is inside the action space)
+        ok.enable_episode_counters()
+        for _ in range(3):
+            ok.step(a)
+        tot = ok.read_episode_counters().cpu().numpy()
+        ok.warn_diagnostics()
+    msgs = [str(x.message) for x in w]
+    assert not any('found no valid' in m for m in msgs) and any('600 env-step(s) had an action outside the action space' in m for m in msgs), msgs
+    assert ok.diagnostics() == {'reset_exhausted': 0, 'actions_clipped': 600} and tot[7] == 600 and tot[6] == 0 and len(tot) == 8
+    ok.count_clipped_actions(False)
+    ok.step(a)
+    assert ok.diagnostics()['actions_clipped'] == 600
+    env.close(); ok.close()
