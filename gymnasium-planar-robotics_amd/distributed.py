@@ -71,6 +71,20 @@ def _all_gather_bytes(recv: torch.Tensor, send: torch.Tensor) -> None:
         dist.all_gather_into_tensor(recv, send)
 
 
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """ONE all_reduce (SUM) of a small tensor over the default process group -- the episode counters' collective. RCCL reduces device
+    memory in place; the gloo rehearsal backend goes through the host. Returns the reduced tensor on ``t``'s device (``t`` itself when
+    there is nothing to reduce with)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if dist.get_backend() == 'gloo' and t.is_cuda:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        return host.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 @dataclass
 class _Field:
     name: str

@@ -321,18 +321,10 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
     def all_reduce_episode_counters(self) -> torch.Tensor:
         """Job-wide totals: ONE all_reduce (SUM) of the eight counters over the default process group -- the only collective a
         rollout flush needs when every rank's learner consumes its own shard."""
-        import torch.distributed as dist
+        from .. import distributed
         if not getattr(self, '_counters_on', False):
             self.enable_episode_counters()
-        tot = self.read_episode_counters().clone()
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == 'gloo':
-                host = tot.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                tot = host.to(self.device)
-            else:
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        return tot
+        return distributed.all_reduce_sum(self.read_episode_counters().clone())
 
     # ------------------------------------------------------------------------------------------------------------
     # the reference's warnings, batched: counted on the device, reported on the host

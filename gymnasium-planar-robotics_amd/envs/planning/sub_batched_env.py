@@ -214,19 +214,11 @@ class VecBenchmarkPlanningEnvSubBatched:
         return torch.stack([s.read_episode_counters() for s in self.subs]).sum(dim=0)
 
     def all_reduce_episode_counters(self) -> torch.Tensor:
-        import torch.distributed as dist
+        from ... import distributed
         if not all(getattr(s, '_counters_on', False) for s in self.subs):
             self.synchronize()
             self.enable_episode_counters()
-        tot = self.read_episode_counters()
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == 'gloo':
-                host = tot.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                tot = host.to(self.device)
-            else:
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        return tot
+        return distributed.all_reduce_sum(self.read_episode_counters())
 
     def state_dict(self) -> dict[str, Any]:
         self.synchronize()

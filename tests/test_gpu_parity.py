@@ -710,7 +710,7 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device', '--envs-per-gpu', '4096',
-                        '--steps', '30', '--warmup', '10', '--min-seconds', '0.02', '--no-cpu-baseline', '--launch-timeout', '200', '--gather-timeout', '60',
+                        '--steps', '30', '--warmup', '10', '--min-seconds', '0.02', '--extra-seconds', '0.02', '--regions', '3', '--no-cpu-baseline', '--launch-timeout', '200', '--gather-timeout', '60',
                         '--watchdog', '180'], env=env, capture_output=True, text=True, timeout=240)   # (a hang ends with the ranks' stacks in stderr)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
@@ -719,7 +719,8 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 2048
     assert c['strong_scaling']['rollout_launch']['env_steps_per_s'] > 0
     assert 0 < c['done_fraction_per_step'] < 0.5
-    assert c['timed_seconds'] >= 0.02 and c['timed_steps'] % 30 == 0
+    assert c['timed_seconds'] >= 0.06 and c['timed_steps'] % 30 == 0 and c['timed_regions'] == 3 and len(c['headline_spread']['region_seconds']) == 3
+    assert line['strong_value'] == c['strong_scaling']['env_steps_per_s'] > 0
     # north_star's collective is in the DEFAULT line: one all-gather of the [50, E/N, .] rollout buffers per flush, timed
     g = c['rollout_gather']
     assert g['status'] == 'ok' and g['env_steps_per_s'] > 0 and g['minibatch']['env_steps_per_s'] > 0 and g['counters_only']['env_steps_per_s'] > 0
@@ -727,6 +728,26 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     assert c['distributed'] == {'backend': 'gloo', 'world_size_seen_by_backend': 2}
     assert line['roofline']['launches_in_flight'] in (1, 2, 4) and line['roofline']['envs_per_launch'] * line['roofline']['launches_in_flight'] == 4096
     assert line['roofline']['kernel'] == 'gpr::k_step<float, float, 4, false, true, true, 0>'
+
+
+def test_bench_four_ranks_on_one_gpu(gpr):
+    """the launcher, the sharding and all three flush collectives at the largest world size ONE GPU box allows (its process guard admits
+    six GPU processes: this test process + 4 ranks; world size 8 runs over gloo on the CPU, tests/test_host_cpu.py)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--backend', 'gloo', '--single-device', '--envs-per-gpu', '4096',
+                        '--steps', '20', '--warmup', '5', '--min-seconds', '0.02', '--extra-seconds', '0.02', '--regions', '2', '--sub-batches', '1',
+                        '--no-cpu-baseline', '--launch-timeout', '250', '--gather-timeout', '90', '--watchdog', '230'],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    c = line['config']
+    assert line['n_gpus'] == 4 and c['distributed'] == {'backend': 'gloo', 'world_size_seen_by_backend': 4}
+    assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 1024 and line['strong_value'] > 0
+    g = c['rollout_gather']
+    assert g['status'] == 'ok' and g['bytes_per_rank_per_flush'] == 50 * 1024 * (4 * 4 * 8 + 4 + 2)
+    assert g['env_steps_per_s'] > 0 and g['minibatch']['env_steps_per_s'] > 0 and g['counters_only']['env_steps_per_s'] > 0
 
 
 def test_bench_dead_rank_fails_fast(gpr):

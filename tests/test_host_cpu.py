@@ -1,5 +1,6 @@
 """CPU tests (no GPU): host-side logic, the C-ABI surface, the multi-process path over gloo, the engine's RNG spec."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -270,6 +271,101 @@ def test_two_process_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f'rank {r} ok' in o, o[-2000:]
+
+
+_WORKER8 = r'''
+import json, os, sys, time, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import gymnasium_planar_robotics_amd as gpr
+from oracle import oracle
+rank, local_rank, world = gpr.distributed.init_from_env('gloo')
+assert world == 8 and dist.get_backend() == 'gloo' and dist.get_world_size() == 8
+# (1) BASELINE's strong shape: 65 536 envs over 8 ranks -> [50, 8192, .] per rank, 4 movers: ONE all-gather of the whole buffer
+E_glob, M, T = 65536, 4, 50
+start, stop = gpr.distributed.shard_range(E_glob, rank, world)
+assert stop - start == 8192
+buf = gpr.distributed.RolloutBuffer(T, stop - start, M, 2 * M, dtype=torch.float32, device='cpu')
+ids = torch.arange(start, stop, dtype=torch.float32)
+for t in range(T):
+    s = buf.slot(t)
+    s['reward'].copy_(ids + 0.25 * t)
+    s['observation'][:, 0].copy_(ids * 2)
+    s['truncated'].copy_(((torch.arange(start, stop) + t) % 3 == 0).to(torch.uint8))
+t0 = time.perf_counter()
+g = buf.flush()
+dt_flush = time.perf_counter() - t0
+assert g['reward'].shape == (8, T, 8192) and g['observation'].shape == (8, T, 8192, 2 * M)
+whole = g['reward'].permute(1, 0, 2).reshape(T, E_glob)
+assert torch.equal(whole[7], torch.arange(E_glob, dtype=torch.float32) + 1.75)
+assert torch.equal(g['observation'][5, 49, :, 0], torch.arange(5 * 8192, 6 * 8192, dtype=torch.float32) * 2)
+assert torch.equal(g['truncated'].permute(1, 0, 2).reshape(T, E_glob)[4], ((torch.arange(E_glob) + 4) % 3 == 0).to(torch.uint8))
+# (2) the learner minibatch: [50, 1024, .] of every rank, ONE all-gather
+mb = buf.gather_minibatch(1024, start=100)
+assert mb['reward'].shape == (8, T, 1024)
+for r in range(8):
+    assert torch.equal(mb['reward'][r, 3], torch.arange(r * 8192 + 100, r * 8192 + 1124, dtype=torch.float32) + 0.75)
+# (3) the counters' all-reduce: eight uint64 totals per rank, ONE all_reduce
+tot = gpr.distributed.all_reduce_sum(torch.arange(8, dtype=torch.int64) * (rank + 1))
+assert torch.equal(tot, torch.arange(8, dtype=torch.int64) * 36)
+# (4) unequal shards are refused at construction on EVERY rank (65 539 envs over 8 ranks: three ranks hold one env more)
+s0, s1 = gpr.distributed.shard_range(65539, rank, world)
+try:
+    gpr.distributed.RolloutBuffer(2, s1 - s0, M, 2 * M, dtype=torch.float32, device='cpu')
+    raise SystemExit('unequal shards were accepted')
+except ValueError as e:
+    assert 'different shard sizes' in str(e)
+# (5) random streams are keyed by GLOBAL env id: shard r of 8 reproduces envs [r E/8, (r+1) E/8) of the single batch, on the oracle
+# (the engine's statement of reset / step / auto-reset): reset + 12 steps incl. auto-resets, sigma = 1e-5
+Eo = 1024
+a0, a1 = gpr.distributed.shard_range(Eo, rank, world)
+rng = np.random.default_rng(5)
+acts = rng.uniform(-10, 10, size=(12, Eo, 2 * M))
+mine = oracle.OraclePlanningEnv(np.ones((6, 6)), M, a1 - a0, std_noise=1e-5, env_id_offset=a0)
+mine.reset(seed=11)
+for t in range(12):
+    res = mine.step(acts[t, a0:a1])
+send = torch.as_tensor(np.concatenate([mine.pos, mine.goal, res['observation'], res['reward'][:, None], res['terminated'][:, None].astype(np.float64)], axis=1))
+send = send.contiguous().reshape(-1)
+recv = torch.empty(world * send.numel(), dtype=send.dtype)
+dist.all_gather_into_tensor(recv, send)
+if rank == 0:
+    one = oracle.OraclePlanningEnv(np.ones((6, 6)), M, Eo, std_noise=1e-5)
+    one.reset(seed=11)
+    n_done = 0
+    for t in range(12):
+        r1 = one.step(acts[t])
+        n_done += int((r1['terminated'] | r1['truncated']).sum())
+    want = np.concatenate([one.pos, one.goal, r1['observation'], r1['reward'][:, None], r1['terminated'][:, None].astype(np.float64)], axis=1)
+    assert n_done > Eo // 2, n_done
+    assert np.array_equal(recv.reshape(Eo, -1).numpy(), want), 'a shard does not reproduce its envs of the single batch'
+    print(json.dumps({'world_size_seen_by_backend': dist.get_world_size(), 'backend': dist.get_backend(), 'flush_bytes_per_rank': buf.nbytes,
+                      'flush_seconds_gloo_loopback': dt_flush, 'envs_compared_with_the_single_batch': Eo, 'auto_resets_in_the_comparison': n_done}))
+dist.barrier(); dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_eight_process_rehearsal_over_gloo(tmp_path):
+    """world size 8 without GPUs (SURVEY 8e; the driver's SCALE run is the only place 8 GPUs exist): the whole-buffer flush at BASELINE's
+    strong shape ([50, 8192, .] = 56 MB per rank), the minibatch gather, the counters' all-reduce, the refusal of unequal shards, and the
+    global-env-id invariance of every shard against the single batch on the oracle"""
+    script = tmp_path / 'worker8.py'
+    script.write_text(_WORKER8)
+    port = 31000 + os.getpid() % 2000
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='8', OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=280)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f'rank {r} ok' in o, o[-2000:]
+    rec = json.loads([ln for ln in outs[0].splitlines() if ln.startswith('{')][-1])
+    assert rec['world_size_seen_by_backend'] == 8 and rec['flush_bytes_per_rank'] == 50 * 8192 * (4 * 4 * 8 + 4 + 2)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'rehearsal_world8.json'), 'w') as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
 
 
 # ----------------------------------------------------------------------------------------------------------------------
