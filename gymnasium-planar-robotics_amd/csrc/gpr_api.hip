@@ -314,7 +314,7 @@ template <typename RT> void fill_push(const gpr_env &e, const gpr_push_params &p
     q.mu = (RT)pp.friction_contact; q.tc = (RT)pp.contact_timeconst;
     q.obj_noise = (RT)pp.object_noise; q.min_mo_dist = (RT)pp.min_mo_dist;
     q.omin_x = (RT)pp.obj_min_xy[0]; q.omin_y = (RT)pp.obj_min_xy[1]; q.omax_x = (RT)pp.obj_max_xy[0]; q.omax_y = (RT)pp.obj_max_xy[1];
-    const double reach = std::sqrt(ax * ax + ay * ay) + h * std::sqrt(2.0);
+    const double reach = std::sqrt(ax * ax + ay * ay) + h * std::sqrt(2.0) + 1e-4;  // (+ the contact margin of gpr-push-v3, PUSH3_MARGIN)
     q.reach2 = (RT)(reach * reach);
 }
 

@@ -13,18 +13,12 @@
 // ~6 clocks each for a lone wavefront) is the kernel's duration at every batch size up to one wavefront per SIMD. More wavefronts per
 // SIMD do not hide it, they share the SIMD: 2 per SIMD +30 %, 4 per SIMD +85 % (same script).
 // The two-mover float kernel does better than redundancy with its lanes: k_push<..., PAIR = true> gives each (mover, object) pair a lane
-// of its own (push_cycle_pair below; 4 096 envs: 131 -> 105.5 us), taken while the grid stays within two wavefronts per SIMD.
+// of its own (push_cycle_pair below), taken while the grid stays within two wavefronts per SIMD.
 //
 // Pinned by the reference: control + clamp (PU:419-448), wall check (BE:426-788), obs / info / reward / terminated (PU:457-607),
-// reset sampling (PU:373-417). The contact physics is the engine's own planar model "gpr-push-v2" (parity unpinned: the
-// reference hands it to MuJoCo) -- see include/gpr.h and DESIGN.md section 9. The double builds run push_cycle, which is
-// oracle/gpr_oracle.c:push_cycle operation for operation (1e-9 on every state in the tests); the float build runs
-// push_cycle_fast, the same model written for the fewest instructions (equal up to float rounding).
-//
-// Everything a cycle touches lives in registers: the contact points of a pair are at most PUSH_SLOTS entries of fixed register
-// arrays (written through unrolled selects, never indexed dynamically -- the first version kept them in scratch memory and
-// spent its time waiting for it), their effective masses are inverted once per cycle, and the contact block of a pair is
-// entered only by wavefronts in which some env's circumscribed circles overlap.
+// reset sampling (PU:373-417). The contact physics is the engine's own planar model "gpr-push-v3" (parity unpinned: the
+// reference hands it to MuJoCo) -- see include/gpr.h and DESIGN.md section 9: ONE templated implementation (push_cycle3) for every
+// precision, oracle/gpr_oracle.c:push_cycle operation for operation (1e-9 on every state in the double builds' tests).
 #include <cstdlib>
 
 #include "gpr.h"
@@ -33,452 +27,297 @@
 
 namespace gpr {
 
-constexpr int PUSH_SLOTS = 4;
-
 template <typename RT> struct Body { RT x, y, th, vx, vy, w; };
-template <typename RT> struct PushPair {
-    int np;
-    RT nx, ny;
-    RT rmx[PUSH_SLOTS], rmy[PUSH_SLOTS], rox[PUSH_SLOTS], roy[PUSH_SLOTS], rmn[PUSH_SLOTS], ron[PUSH_SLOTS], rmt[PUSH_SLOTS], rot_[PUSH_SLOTS];
-    RT inv_kn[PUSH_SLOTS], inv_kt[PUSH_SLOTS], bias[PUSH_SLOTS], jn[PUSH_SLOTS], jt[PUSH_SLOTS];
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Engine contact model "gpr-push-v3" -- oracle/gpr_oracle.c (push3_geometry, push3_lcp2, push3_visit, push_cycle) operation for
+// operation, ONE templated implementation for every precision: the fused operations are exactly the oracle's fma()s, divisions and
+// roots go through Math<RT> (correctly rounded in double; reciprocal / rsqrt instructions in float), sin / cos through the device's.
+// Per (mover, object) pair, in the MOVER's frame: broad phase, separating axes (mover x, mover y, object x, object y; the first smallest
+// overlap wins) -> contact normal + reference / incident box; the incident face's segment cut to the reference face's lateral extent
+// -> at most TWO contact points with depths; two normal rows + ONE friction row at the points' midpoint; block Gauss-Seidel on the
+// cycle's TOTAL impulses: a visit solves the pair's 2 x 2 normal block exactly (enumerated active sets) with the friction impulse held,
+// then clamps the friction impulse to mu (l0 + l1); two visits per pair and cycle. (v2: up to four "vertex inside the other box" points,
+// a friction row per point, four sweeps of scalar sequential impulses: ~600 instructions per contact cycle; v3: ~350.)
+// Everything lives in registers; the contact block of a pair is entered only by wavefronts in which some env's circumscribed circles
+// overlap, the solve only by wavefronts with an env in contact.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float csign_(float mag, float sgn) { return __builtin_copysignf(mag, sgn); }
+__device__ __forceinline__ double csign_(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
+__device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double min_(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }
+
+constexpr double PUSH3_MARGIN = 1e-4;  // contact margin [m]: closer boxes touch; an incident end up to the margin above the reference face is a speculative row
+template <typename RT> struct P3Pair {
+    int np;                        // 0, 1, 2 contact points of this env's pair
+    RT nx, ny;                     // contact normal, mover -> object, world frame
+    RT rmn0, rmn1, ron0, ron1;     // lever arms x n of the two normal rows (mover's, object's)
+    RT rmt, rot_;                  // lever arms x t of the friction row, t = (-ny, nx)
+    RT bias0, bias1;
+    RT a00, a01, a11, att, ant0, ant1;  // A = J M^-1 J^T of the three rows
+    RT i00, i11, idet, itt;        // 1 / a00, 1 / a11, 1 / (a00 a11 - a01^2), 1 / att
+    RT l0, l1, jt;                 // total impulses of the cycle so far
 };
 
-template <typename RT> __device__ __forceinline__ RT cross2(RT ax, RT ay, RT bx, RT by) { return ax * by - ay * bx; }
-
-// one control cycle of the NM movers and the object: oracle/gpr_oracle.c push_cycle operation for operation (the double builds;
-// instantiated for float too, where push_cycle_fast below is what runs)
-template <typename RT, int NM>
-__device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT> (&mv)[NM], Body<RT> &o, const R2<RT> (&u)[NM]) {
-    // 1. external forces
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        Body<RT> &m = mv[i];
-        m.vx = m.vx + dt * u[i].x;
-        m.vy = m.vy + dt * u[i].y;
-        m.w = Math<RT>::div_(m.w + dt * (Q.Kr * ((RT)0 - m.th)) * Q.inv_Im, (RT)1 + dt * Q.Dr * Q.inv_Im);
+// 1. external forces: a mover's actuation and yaw impedance (PU:305-319, IMP:42-47, PU:261-267; damping implicit); the object's joint
+// damping (PU:335, implicit) and Coulomb + torsional friction against the tile, never reversing the motion
+template <typename RT> __device__ __forceinline__ void p3_forces_mover(const PushCst<RT> &Q, RT dt, Body<RT> &m, R2<RT> u) {
+    m.vx = fma_(dt, u.x, m.vx);
+    m.vy = fma_(dt, u.y, m.vy);
+    m.w = Math<RT>::div_(fma_(-(dt * Q.Kr * Q.inv_Im), m.th, m.w), (RT)1 + dt * Q.Dr * Q.inv_Im);
+}
+template <typename RT> __device__ __forceinline__ void p3_forces_object(const PushCst<RT> &Q, Body<RT> &o) {
+    const RT vx = o.vx * Q.damp_lin, vy = o.vy * Q.damp_lin, w = Math<RT>::div_(o.w, Q.damp_rot_den);
+    const RT sp2 = fma_(vx, vx, vy * vy);
+    RT kf;
+    if constexpr (Math<RT>::literal) {
+        const RT sp = Math<RT>::sqrt_(sp2);
+        kf = sp > Q.fric_dv ? Math<RT>::div_(sp - Q.fric_dv, sp) : (RT)0;
+    } else {
+        kf = sp2 > Q.fric_dv * Q.fric_dv ? fma_(-Q.fric_dv, Math<RT>::rsqrt_(sp2), (RT)1) : (RT)0;  // (sp - dv) / sp
     }
-    o.vx = o.vx * Q.damp_lin; o.vy = o.vy * Q.damp_lin;
-    o.w = Math<RT>::div_(o.w, Q.damp_rot_den);
-    {
-        const RT sp = Math<RT>::sqrt_(o.vx * o.vx + o.vy * o.vy);
-        if (sp <= Q.fric_dv) { o.vx = (RT)0; o.vy = (RT)0; } else { const RT k = Math<RT>::div_(sp - Q.fric_dv, sp); o.vx = o.vx * k; o.vy = o.vy * k; }
-        const RT aw = absr(o.w);
-        if (aw <= Q.fric_dw) o.w = (RT)0; else o.w = o.w * Math<RT>::div_(aw - Q.fric_dw, aw);
-    }
-    // 2. contact geometry per pair (mover i, object)
-    PushPair<RT> pr[NM];
-    bool any_contact = false;
-    const RT sx[4] = {-1, -1, 1, 1}, sy[4] = {-1, 1, 1, -1};
-    RT so = (RT)0, co = (RT)1;
-    bool have_o = false;
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        const Body<RT> &m = mv[i];
-        PushPair<RT> &q = pr[i];
-        q.np = 0; q.nx = (RT)0; q.ny = (RT)0;
-        const RT dx = o.x - m.x, dy = o.y - m.y;
-        const bool in_range = !(dx * dx + dy * dy > Q.reach2);  // broad phase: the circumscribed circles overlap
-        if (__ballot(in_range) == 0ull) continue;
-        if (!have_o) { Math<RT>::sincos_(o.th, so, co); have_o = true; }
-        RT sm, cm;
-        Math<RT>::sincos_(m.th, sm, cm);
-        const RT ex4[4] = {cm, -sm, co, -so}, ey4[4] = {sm, cm, so, co};
-        RT best = Math<RT>::inf(), nx = (RT)0, ny = (RT)0;
-        bool touching = in_range;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {  // separating-axis test over the 4 face normals
-            const RT ex = ex4[k], ey = ey4[k];
-            const RT rm = Q.ax * absr(ex * cm + ey * sm) + Q.ay * absr(-ex * sm + ey * cm);
-            const RT ro = Q.h * absr(ex * co + ey * so) + Q.h * absr(-ex * so + ey * co);
-            const RT d = dx * ex + dy * ey;
-            const RT overlap = rm + ro - absr(d);
-            if (touching) {
-                if (overlap < (RT)0) touching = false;
-                else if (overlap < best) { best = overlap; nx = d < (RT)0 ? -ex : ex; ny = d < (RT)0 ? -ey : ey; }
-            }
-        }
-        if (__ballot(touching) == 0ull) continue;
-        any_contact = true;
-        // contact points: object vertices inside the mover, then mover vertices inside the object (at most PUSH_SLOTS, in this
-        // order); depth along n. Slot `np` is addressed through unrolled selects: the arrays stay in registers.
-        RT cx[PUSH_SLOTS] = {0, 0, 0, 0}, cy[PUSH_SLOTS] = {0, 0, 0, 0}, dep[PUSH_SLOTS] = {0, 0, 0, 0};
-        int np = 0;
-        auto add_point = [&](bool inside, RT vx, RT vy, RT d) {
-#pragma unroll
-            for (int s = 0; s < PUSH_SLOTS; ++s) {
-                const bool w = inside & (np == s);
-                cx[s] = w ? vx : cx[s]; cy[s] = w ? vy : cy[s]; dep[s] = w ? d : dep[s];
-            }
-            np += (int)(inside & (np < PUSH_SLOTS));
-        };
-        const RT rm_n = Q.ax * absr(nx * cm + ny * sm) + Q.ay * absr(-nx * sm + ny * cm);
-        const RT ro_n = Q.h * absr(nx * co + ny * so) + Q.h * absr(-nx * so + ny * co);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const RT vx = o.x + co * (sx[k] * Q.h) - so * (sy[k] * Q.h), vy = o.y + so * (sx[k] * Q.h) + co * (sy[k] * Q.h);
-            const RT lx = (vx - m.x) * cm + (vy - m.y) * sm, ly = -(vx - m.x) * sm + (vy - m.y) * cm;
-            add_point(touching & (absr(lx) <= Q.ax) & (absr(ly) <= Q.ay), vx, vy, rm_n - ((vx - m.x) * nx + (vy - m.y) * ny));
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const RT vx = m.x + cm * (sx[k] * Q.ax) - sm * (sy[k] * Q.ay), vy = m.y + sm * (sx[k] * Q.ax) + cm * (sy[k] * Q.ay);
-            const RT lx = (vx - o.x) * co + (vy - o.y) * so, ly = -(vx - o.x) * so + (vy - o.y) * co;
-            add_point(touching & (absr(lx) <= Q.h) & (absr(ly) <= Q.h), vx, vy, ro_n + ((vx - o.x) * nx + (vy - o.y) * ny));
-        }
-        if (touching & (np == 0)) { cx[0] = m.x + (RT)0.5 * dx; cy[0] = m.y + (RT)0.5 * dy; dep[0] = best; np = 1; }
-        q.np = np; q.nx = nx; q.ny = ny;
-        const RT tx = -ny, ty = nx;
-#pragma unroll
-        for (int k = 0; k < PUSH_SLOTS; ++k) {
-            if (__ballot(k < np) == 0ull) break;
-            q.rmx[k] = cx[k] - m.x; q.rmy[k] = cy[k] - m.y; q.rox[k] = cx[k] - o.x; q.roy[k] = cy[k] - o.y;
-            q.rmn[k] = cross2(q.rmx[k], q.rmy[k], nx, ny); q.ron[k] = cross2(q.rox[k], q.roy[k], nx, ny);
-            q.rmt[k] = cross2(q.rmx[k], q.rmy[k], tx, ty); q.rot_[k] = cross2(q.rox[k], q.roy[k], tx, ty);
-            q.inv_kn[k] = Math<RT>::div_((RT)1, Q.inv_mm + Q.inv_mo + q.rmn[k] * q.rmn[k] * Q.inv_Im + q.ron[k] * q.ron[k] * Q.inv_Io);
-            q.inv_kt[k] = Math<RT>::div_((RT)1, Q.inv_mm + Q.inv_mo + q.rmt[k] * q.rmt[k] * Q.inv_Im + q.rot_[k] * q.rot_[k] * Q.inv_Io);
-            q.bias[k] = Math<RT>::div_(dep[k] > (RT)0 ? dep[k] : (RT)0, Q.tc);
-            q.jn[k] = (RT)0; q.jt[k] = (RT)0;
-        }
-    }
-    // 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points
-    if (any_contact) {  // (wave-uniform)
-        for (int it = 0; it < 4; ++it) {
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                Body<RT> &m = mv[i];
-                PushPair<RT> &q = pr[i];
-                const RT nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
-#pragma unroll
-                for (int k = 0; k < PUSH_SLOTS; ++k) {
-                    if (__ballot(k < q.np) == 0ull) break;
-                    if (k < q.np) {
-                        const RT rmx = q.rmx[k], rmy = q.rmy[k], rox = q.rox[k], roy = q.roy[k];
-                        RT rvx = (o.vx - o.w * roy) - (m.vx - m.w * rmy), rvy = (o.vy + o.w * rox) - (m.vy + m.w * rmx);
-                        RT dj = -((rvx * nx + rvy * ny) - q.bias[k]) * q.inv_kn[k];
-                        RT jn_new = q.jn[k] + dj; if (jn_new < (RT)0) jn_new = (RT)0;
-                        dj = jn_new - q.jn[k]; q.jn[k] = jn_new;
-                        m.vx -= dj * nx * Q.inv_mm; m.vy -= dj * ny * Q.inv_mm; m.w -= dj * q.rmn[k] * Q.inv_Im;
-                        o.vx += dj * nx * Q.inv_mo; o.vy += dj * ny * Q.inv_mo; o.w += dj * q.ron[k] * Q.inv_Io;
-                        rvx = (o.vx - o.w * roy) - (m.vx - m.w * rmy); rvy = (o.vy + o.w * rox) - (m.vy + m.w * rmx);
-                        RT djt = -(rvx * tx + rvy * ty) * q.inv_kt[k];
-                        const RT lim = Q.mu * q.jn[k];
-                        RT jt_new = q.jt[k] + djt;
-                        if (jt_new > lim) jt_new = lim;
-                        if (jt_new < -lim) jt_new = -lim;
-                        djt = jt_new - q.jt[k]; q.jt[k] = jt_new;
-                        m.vx -= djt * tx * Q.inv_mm; m.vy -= djt * ty * Q.inv_mm; m.w -= djt * q.rmt[k] * Q.inv_Im;
-                        o.vx += djt * tx * Q.inv_mo; o.vy += djt * ty * Q.inv_mo; o.w += djt * q.rot_[k] * Q.inv_Io;
-                    }
-                }
-            }
-        }
-    }
-    // 4. positions with the new velocities
-#pragma unroll
-    for (int i = 0; i < NM; ++i) { Body<RT> &m = mv[i]; m.x += dt * m.vx; m.y += dt * m.vy; m.th += dt * m.w; }
-    o.x += dt * o.vx; o.y += dt * o.vy; o.th += dt * o.w;
+    o.vx = vx * kf; o.vy = vy * kf;
+    const RT aw = absr(w);
+    o.w = aw <= Q.fric_dw ? (RT)0 : csign_(aw - Q.fric_dw, w);
 }
 
-// THROUGHPUT FORM of push_cycle (float arithmetic only): the same model, the same order of the sequential impulses, written for
-// the fewest vector instructions -- one lane per env and one wavefront per SIMD at 65 536 envs means the kernel lasts as long as
-// the instruction chain of a wavefront in which some env is in contact, ~1 000 instructions per cycle in the literal form above:
-//   * the geometry of a pair lives in the MOVER's frame: one relative rotation, two of the four SAT axes are coordinate axes,
-//     the object's vertices are four sums and the mover's are constants;
-//   * the eight "vertex inside the other box" tests only set bits of a mask; the (at most PUSH_SLOTS) contact points are then
-//     rebuilt from their bit index -- no register arrays written through selects;
-//   * the relative velocity at a contact point along n / t is n.(vo - vm) + wo (ro x n) - wm (rm x n): the lever arms
-//     themselves are never stored, the products with the inverse masses / inertias are formed once per cycle.
-// Equal to push_cycle up to float rounding (tests/test_gpu_pushing.py holds the float build to the oracle through it).
-// POSITIONS ARE DISPLACEMENTS. A body's x, y here are its displacement since the start of the env-step (at most 8 cm: float ulp 7e-9 m) and
-// rel0[i] is object - mover i at the step's start, formed once in double: the geometry only ever needs object - mover. Summing the
-// 1e-3-sized per-cycle increments onto ~0.4 m positions in float instead put 3e-8 m of rounding into every cycle, and a contact
-// manifold changes discretely (a vertex enters or leaves a face, the axis of least overlap switches) wherever such an error decides:
-// the float build then pushes the 10 g object one cycle earlier or later than the fp64 oracle -- the "events" of tests/test_gpu_pushing.py.
-// the contact points of one (mover, object) pair in the throughput form
-struct FastPair {
-    int np, npw;  // contact points of this env's pair; the most of any env of the wavefront (scalar: bounds the slot loops)
-    float nx, ny;
-    float rmn[PUSH_SLOTS], ron[PUSH_SLOTS], rmt[PUSH_SLOTS], rot_[PUSH_SLOTS];  // lever arms x n, x t
-    float wmn[PUSH_SLOTS], won[PUSH_SLOTS], wmt[PUSH_SLOTS], wot[PUSH_SLOTS];   // ... times the inverse inertias
-    float inv_kn[PUSH_SLOTS], inv_kt[PUSH_SLOTS], bias[PUSH_SLOTS], jn[PUSH_SLOTS], jt[PUSH_SLOTS];
-};
-
-// 1. external forces: a mover's actuation and yaw impedance; the object's damping and friction against the tile
-__device__ __forceinline__ void fast_forces_mover(const PushCst<float> &Q, float dt, Body<float> &m, R2<float> u) {
-    const float w_gain = dt * Q.Kr * Q.inv_Im, w_den = __builtin_amdgcn_rcpf(1.f + dt * Q.Dr * Q.inv_Im);
-    m.vx = __builtin_fmaf(dt, u.x, m.vx);
-    m.vy = __builtin_fmaf(dt, u.y, m.vy);
-    m.w = __builtin_fmaf(-w_gain, m.th, m.w) * w_den;
-}
-__device__ __forceinline__ void fast_forces_object(const PushCst<float> &Q, Body<float> &o) {
-    const float vx = o.vx * Q.damp_lin, vy = o.vy * Q.damp_lin, w = o.w * __builtin_amdgcn_rcpf(Q.damp_rot_den);
-    const float sp2 = __builtin_fmaf(vx, vx, vy * vy);
-    const float k = sp2 > Q.fric_dv * Q.fric_dv ? __builtin_fmaf(-Q.fric_dv, __builtin_amdgcn_rsqf(sp2), 1.f) : 0.f;  // (sp - dv) / sp
-    o.vx = vx * k; o.vy = vy * k;
-    const float aw = __builtin_fabsf(w);
-    o.w = aw <= Q.fric_dw ? 0.f : __builtin_copysignf(aw - Q.fric_dw, w);
-}
-
-// 2. contact geometry of the pair (mover m, object), in the mover's frame. Returns whether some env of the wavefront touches (wave-uniform);
-// q.npw stays 0 otherwise and the slots hold nothing. so / co: sine and cosine of the object's yaw, formed on first use (have_o).
-__device__ __forceinline__ bool fast_pair_geometry(const PushCst<float> &Q, const Body<float> &m, const Body<float> &o, R2<float> rel0, float &so, float &co,
-                                                   bool &have_o, float imm, float inv_tc, FastPair &q) {
-    q.np = 0; q.npw = 0; q.nx = 0.f; q.ny = 0.f;
-    const float dx = rel0.x + (o.x - m.x), dy = rel0.y + (o.y - m.y);
-    const bool in_range = !(__builtin_fmaf(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
+// 2. contact geometry of the pair (mover m, object o); dx, dy = object centre - mover centre (world). Returns whether some env of the
+// wavefront has a contact point (wave-uniform); q.np == 0 for the lanes without one (their rows hold finite junk that nothing uses).
+template <typename RT>
+__device__ __forceinline__ bool p3_geometry(const PushCst<RT> &Q, RT dt, const Body<RT> &m, const Body<RT> &o, RT dx, RT dy, P3Pair<RT> &q) {
+    q.np = 0; q.nx = (RT)0; q.ny = (RT)0; q.l0 = (RT)0; q.l1 = (RT)0; q.jt = (RT)0;
+    // (a pair whose block is left early keeps finite rows: with two movers the other pair's contact sends every lane through the visits,
+    //  where this pair's impulses are selected to zero and multiplied with its rows)
+    q.rmn0 = q.rmn1 = q.ron0 = q.ron1 = q.rmt = q.rot_ = q.bias0 = q.bias1 = (RT)0;
+    q.a00 = q.a11 = q.att = (RT)1; q.a01 = q.ant0 = q.ant1 = (RT)0; q.i00 = q.i11 = q.idet = q.itt = (RT)1;
+    const bool in_range = !(fma_(dx, dx, dy * dy) > Q.reach2);  // broad phase: the circumscribed circles overlap
     if (__ballot(in_range) == 0ull) return false;
-    if (!have_o) { Math<float>::sincos_(o.th, so, co); have_o = true; }
-    float sm, cm;
-    Math<float>::sincos_(m.th, sm, cm);
-    const float c = __builtin_fmaf(co, cm, so * sm), s = __builtin_fmaf(so, cm, -(co * sm));  // the object's axes in the mover's frame: (c, s), (-s, c)
-    const float lx = __builtin_fmaf(dx, cm, dy * sm), ly = __builtin_fmaf(dy, cm, -(dx * sm)); // the object's centre in the mover's frame
-    const float ac = __builtin_fabsf(c), as = __builtin_fabsf(s);
-    // separating axes in the order of push_cycle: mover x, mover y, object x, object y; the first smallest overlap wins
-    const float ro01 = Q.h * (ac + as);
-    const float d2 = __builtin_fmaf(lx, c, ly * s), d3 = __builtin_fmaf(ly, c, -(lx * s));
-    const float ov0 = (Q.ax + ro01) - __builtin_fabsf(lx), ov1 = (Q.ay + ro01) - __builtin_fabsf(ly);
-    const float ov2 = (__builtin_fmaf(Q.ax, ac, Q.ay * as) + Q.h) - __builtin_fabsf(d2);
-    const float ov3 = (__builtin_fmaf(Q.ax, as, Q.ay * ac) + Q.h) - __builtin_fabsf(d3);
-    const bool touching = in_range & !(__builtin_fminf(__builtin_fminf(ov0, ov1), __builtin_fminf(ov2, ov3)) < 0.f);
-    if (__ballot(touching) == 0ull) return false;
-    float best = ov0, nlx = __builtin_copysignf(1.f, lx), nly = 0.f;  // the normal in the mover's frame, towards the object
-    { const bool t = ov1 < best; best = t ? ov1 : best; nlx = t ? 0.f : nlx; nly = t ? __builtin_copysignf(1.f, ly) : nly; }
-    { const bool t = ov2 < best; best = t ? ov2 : best; nlx = t ? __builtin_copysignf(c, c * d2) : nlx; nly = t ? __builtin_copysignf(s, s * d2) : nly; }
-    { const bool t = ov3 < best; best = t ? ov3 : best; nlx = t ? __builtin_copysignf(s, -(s * d3)) : nlx; nly = t ? __builtin_copysignf(c, c * d3) : nly; }
-    const float nx = __builtin_fmaf(nlx, cm, -(nly * sm)), ny = __builtin_fmaf(nlx, sm, nly * cm);
-    const float rm_n = __builtin_fmaf(Q.ax, __builtin_fabsf(nlx), Q.ay * __builtin_fabsf(nly));
-    const float ro_n = Q.h * (__builtin_fabsf(__builtin_fmaf(nlx, c, nly * s)) + __builtin_fabsf(__builtin_fmaf(nly, c, -(nlx * s))));
-    // candidates: bit k = object vertex k inside the mover, bit 4 + k = mover vertex k inside the object (vertex order of push_cycle)
-    const float hc = Q.h * c, hs = Q.h * s, e1 = hc - hs, e2 = hc + hs;
-    auto in_m = [&](float vx, float vy) { return (__builtin_fabsf(vx) <= Q.ax) & (__builtin_fabsf(vy) <= Q.ay); };
-    const float qxm = -Q.ax - lx, qxp = Q.ax - lx, qym = -Q.ay - ly, qyp = Q.ay - ly;  // mover vertices relative to the object's centre
-    const float qyms = qym * s, qyps = qyp * s, qxms = qxm * s, qxps = qxp * s;
-    auto in_o = [&](float qx, float qy, float qys, float qxs) {
-        return (__builtin_fabsf(__builtin_fmaf(qx, c, qys)) <= Q.h) & (__builtin_fabsf(__builtin_fmaf(qy, c, -qxs)) <= Q.h);
-    };
-    unsigned mask = (in_m(lx - e1, ly - e2) ? 1u : 0u) | (in_m(lx - e2, ly + e1) ? 2u : 0u) | (in_m(lx + e1, ly + e2) ? 4u : 0u) |
-                    (in_m(lx + e2, ly - e1) ? 8u : 0u) | (in_o(qxm, qym, qyms, qxms) ? 16u : 0u) | (in_o(qxm, qyp, qyps, qxms) ? 32u : 0u) |
-                    (in_o(qxp, qyp, qyps, qxps) ? 64u : 0u) | (in_o(qxp, qym, qyms, qxps) ? 128u : 0u);
-    mask = touching ? mask : 0u;
-    const bool lone = touching & (mask == 0u);  // boxes overlap but no vertex is inside the other: one point between the centres
-    const int np_raw = __popc(mask);
-    const int np = lone ? 1 : (np_raw < PUSH_SLOTS ? np_raw : PUSH_SLOTS);
-    q.np = np; q.nx = nx; q.ny = ny;
-    // (one wave-level decision per pair and cycle instead of one per slot and sweep: the loops below are scalar-bounded)
-    const int npw = __ballot(np > 1) == 0ull ? 1 : __ballot(np > 2) == 0ull ? 2 : __ballot(np > 3) == 0ull ? 3 : 4;
-    q.npw = npw;
-#pragma unroll
-    for (int k = 0; k < PUSH_SLOTS; ++k) {
-        if (k >= npw) break;
-        const int idx = mask != 0u ? __builtin_ctz(mask) : 0;
-        mask &= mask - 1u;
-        const bool of_mover = idx >= 4;
-        const float sxf = (idx & 2) ? 1.f : -1.f, syf = ((idx + 1) & 2) ? 1.f : -1.f;
-        // the point in the mover's frame and its depth along n
-        float px = of_mover ? sxf * Q.ax : __builtin_fmaf(-syf, hs, __builtin_fmaf(sxf, hc, lx));
-        float py = of_mover ? syf * Q.ay : __builtin_fmaf(syf, hc, __builtin_fmaf(sxf, hs, ly));
-        const float pn = of_mover ? __builtin_fmaf(px - lx, nlx, (py - ly) * nly) : -__builtin_fmaf(px, nlx, py * nly);
-        float dep = (of_mover ? ro_n : rm_n) + pn;
-        float rmx = __builtin_fmaf(px, cm, -(py * sm)), rmy = __builtin_fmaf(px, sm, py * cm);
-        if (k == 0) { rmx = lone ? 0.5f * dx : rmx; rmy = lone ? 0.5f * dy : rmy; dep = lone ? best : dep; }
-        const float rox = rmx - dx, roy = rmy - dy;
-        const float rmn = __builtin_fmaf(rmx, ny, -(rmy * nx)), ron = __builtin_fmaf(rox, ny, -(roy * nx));
-        const float rmt = __builtin_fmaf(rmx, nx, rmy * ny), rot = __builtin_fmaf(rox, nx, roy * ny);  // r x t with t = (-ny, nx)
-        q.rmn[k] = rmn; q.ron[k] = ron; q.rmt[k] = rmt; q.rot_[k] = rot;
-        q.wmn[k] = rmn * Q.inv_Im; q.won[k] = ron * Q.inv_Io; q.wmt[k] = rmt * Q.inv_Im; q.wot[k] = rot * Q.inv_Io;
-        q.inv_kn[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmn, q.wmn[k], __builtin_fmaf(ron, q.won[k], imm)));
-        q.inv_kt[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(rmt, q.wmt[k], __builtin_fmaf(rot, q.wot[k], imm)));
-        q.bias[k] = __builtin_fmaxf(dep, 0.f) * inv_tc;
-        q.jn[k] = 0.f; q.jt[k] = 0.f;
-    }
+    RT sm, cm, so, co;
+    Math<RT>::sincos_(m.th, sm, cm);
+    Math<RT>::sincos_(o.th, so, co);
+    const RT c = fma_(co, cm, so * sm), s = fma_(so, cm, -(co * sm));    // the object's axes in the mover's frame: (c, s), (-s, c)
+    const RT lx = fma_(dx, cm, dy * sm), ly = fma_(dy, cm, -(dx * sm));  // the object's centre in the mover's frame
+    const RT ac = absr(c), as = absr(s);
+    const RT ro01 = Q.h * (ac + as);
+    const RT d2 = fma_(lx, c, ly * s), d3 = fma_(ly, c, -(lx * s));
+    const RT ov0 = (Q.ax + ro01) - absr(lx), ov1 = (Q.ay + ro01) - absr(ly);
+    const RT ov2 = (fma_(Q.ax, ac, Q.ay * as) + Q.h) - absr(d2), ov3 = (fma_(Q.ax, as, Q.ay * ac) + Q.h) - absr(d3);
+    bool touch = in_range & !(min_(min_(ov0, ov1), min_(ov2, ov3)) < (RT)-PUSH3_MARGIN);
+    if (__ballot(touch) == 0ull) return false;
+    int k = 0;
+    RT best = ov0;
+    { const bool t = ov1 < best; best = t ? ov1 : best; k = t ? 1 : k; }
+    { const bool t = ov2 < best; best = t ? ov2 : best; k = t ? 2 : k; }
+    { const bool t = ov3 < best; best = t ? ov3 : best; k = t ? 3 : k; }
+    // reference box: centre (rcx, rcy), outward normal (rnx, rny) towards the incident box, half extents en (along the normal) and et
+    // (along the face); incident box: centre (icx, icy), axes (ux, uy), (vx, vy), half extents hu, hv. (nlx, nly): mover -> object.
+    const bool mref = k < 2, kx = (k == 0) | (k == 2);  // the mover's face is the reference face; the axis is an "x" axis of its box
+    const RT sg = csign_((RT)1, k == 2 ? d2 : d3);
+    const RT nlx = mref ? (kx ? csign_((RT)1, lx) : (RT)0) : sg * (kx ? c : -s);
+    const RT nly = mref ? (kx ? (RT)0 : csign_((RT)1, ly)) : sg * (kx ? s : c);
+    const RT rcx = mref ? (RT)0 : lx, rcy = mref ? (RT)0 : ly;
+    const RT rnx = mref ? nlx : -nlx, rny = mref ? nly : -nly;
+    const RT en = mref ? (kx ? Q.ax : Q.ay) : Q.h, et = mref ? (kx ? Q.ay : Q.ax) : Q.h;
+    const RT icx = mref ? lx : (RT)0, icy = mref ? ly : (RT)0;
+    const RT ux = mref ? c : (RT)1, uy = mref ? s : (RT)0, vx = mref ? -s : (RT)0, vy = mref ? c : (RT)1;
+    const RT hu = mref ? Q.h : Q.ax, hv = mref ? Q.h : Q.ay;
+    // incident face: the one whose outward normal is most opposed to the reference normal
+    const RT pu = fma_(rnx, ux, rny * uy), pv = fma_(rnx, vx, rny * vy);
+    const bool fu = absr(pu) >= absr(pv);
+    const RT sgn = -csign_((RT)1, fu ? pu : pv);
+    const RT fx = fu ? sgn * hu * ux : sgn * hv * vx, fy = fu ? sgn * hu * uy : sgn * hv * vy;  // face centre offset from the incident centre
+    const RT ex = fu ? hv * vx : hu * ux, ey = fu ? hv * vy : hu * uy;                          // half edge vector
+    const RT bx = (icx + fx) - rcx, by = (icy + fy) - rcy;                    // face centre relative to the reference centre
+    const RT pax = bx - ex, pay = by - ey, pbx = bx + ex, pby = by + ey;      // the incident segment's ends
+    const RT tx = -rny, ty = rnx;
+    const RT sa = fma_(pax, tx, pay * ty), sb = fma_(pbx, tx, pby * ty);      // lateral coordinates on the reference face
+    const RT da = en - fma_(pax, rnx, pay * rny), db = en - fma_(pbx, rnx, pby * rny);  // depths below the reference face
+    touch = touch & !((min_(sa, sb) > et) | (max_(sa, sb) < -et));            // the segment passes the face by
+    const RT inv = Math<RT>::div_((RT)1, sb - sa);
+    const RT ta = (min_(max_(sa, -et), et) - sa) * inv, tb = (min_(max_(sb, -et), et) - sa) * inv;  // cut to [-et, et] along the segment
+    const RT qx0 = fma_(ta, pbx - pax, pax) + rcx, qy0 = fma_(ta, pby - pay, pay) + rcy, dp0 = fma_(ta, db - da, da);
+    const RT qx1 = fma_(tb, pbx - pax, pax) + rcx, qy1 = fma_(tb, pby - pay, pay) + rcy, dp1 = fma_(tb, db - da, da);
+    // points with depth >= -margin, the deeper one first
+    const bool sw = dp1 > dp0;
+    const RT e0 = sw ? dp1 : dp0, e1 = sw ? dp0 : dp1;
+    touch = touch & !(e0 < (RT)-PUSH3_MARGIN);
+    if (__ballot(touch) == 0ull) return false;
+    bool two = e1 >= (RT)-PUSH3_MARGIN;
+    const RT p0x = sw ? qx1 : qx0, p0y = sw ? qy1 : qy0;
+    const RT p1x = two ? (sw ? qx0 : qx1) : p0x, p1y = two ? (sw ? qy0 : qy1) : p0y;
+    const RT d0 = e0, d1 = two ? e1 : (RT)0;
+    // rows: r x n and r x t are the same in every frame; the mover's lever arm is the point itself, the object's the point - (lx, ly)
+    const RT mxc = (RT)0.5 * (p0x + p1x), myc = (RT)0.5 * (p0y + p1y);        // friction row: midpoint of the points
+    q.rmn0 = fma_(p0x, nly, -(p0y * nlx)); q.ron0 = fma_(p0x - lx, nly, -((p0y - ly) * nlx));
+    q.rmn1 = fma_(p1x, nly, -(p1y * nlx)); q.ron1 = fma_(p1x - lx, nly, -((p1y - ly) * nlx));
+    q.rmt = fma_(mxc, nlx, myc * nly); q.rot_ = fma_(mxc - lx, nlx, (myc - ly) * nly);
+    const RT imm = Q.inv_mm + Q.inv_mo;
+    const RT wm0 = q.rmn0 * Q.inv_Im, wo0 = q.ron0 * Q.inv_Io, wm1 = q.rmn1 * Q.inv_Im, wo1 = q.ron1 * Q.inv_Io;
+    const RT wmt = q.rmt * Q.inv_Im, wot = q.rot_ * Q.inv_Io;
+    q.a00 = fma_(q.rmn0, wm0, fma_(q.ron0, wo0, imm));
+    q.a11 = fma_(q.rmn1, wm1, fma_(q.ron1, wo1, imm));
+    q.a01 = fma_(q.rmn0, wm1, fma_(q.ron0, wo1, imm));
+    q.att = fma_(q.rmt, wmt, fma_(q.rot_, wot, imm));
+    q.ant0 = fma_(q.rmn0, wmt, q.ron0 * wot);
+    q.ant1 = fma_(q.rmn1, wmt, q.ron1 * wot);
+    // two points that (nearly) coincide make the block singular: the deeper one stands for both
+    const RT det = fma_(q.a00, q.a11, -(q.a01 * q.a01));
+    two = two & (det > (RT)1e-4 * (q.a00 * q.a11));
+    q.i00 = Math<RT>::div_((RT)1, q.a00); q.i11 = Math<RT>::div_((RT)1, q.a11); q.idet = Math<RT>::div_((RT)1, det); q.itt = Math<RT>::div_((RT)1, q.att);
+    q.bias0 = Math<RT>::div_(d0, d0 >= (RT)0 ? Q.tc : dt);  // recovery; speculative: the gap may close within the cycle, not more
+    q.bias1 = Math<RT>::div_(d1, d1 >= (RT)0 ? Q.tc : dt);
+    q.nx = fma_(nlx, cm, -(nly * sm)); q.ny = fma_(nlx, sm, nly * cm);
+    q.np = touch ? (two ? 2 : 1) : 0;
     return true;
 }
 
-// 3a. sequential impulses of ONE pair with at most two points in any env of the wavefront (the usual face-to-face push): the same
-// Gauss-Seidel sweeps on the IMPULSES. With b = J V (the relative velocities at the points before any impulse) and A = J M^-1 J^T (formed
-// once per cycle: n.n = t.t = 1, n.t = 0, the lever-arm products are there) the relative velocity along a row is b + A lambda, an update is
-// three fma's on the other rows' impulses instead of re-deriving it from six body velocities and pushing the impulse back into them
-// (14 instead of 35 instructions per point and sweep); the bodies take the summed impulses at the end. A lane without contact
-// (q.np == 0) changes nothing.
-__device__ __forceinline__ void fast_impulse_solve(const PushCst<float> &Q, float imm, Body<float> &m, Body<float> &o, const FastPair &q) {
-    const float nx = q.nx, ny = q.ny;
-    const bool two = q.np > 1;
-    const float dvx = o.vx - m.vx, dvy = o.vy - m.vy, dvn = __builtin_fmaf(dvx, nx, dvy * ny), dvt = __builtin_fmaf(dvy, nx, -(dvx * ny));
-    const float bn0 = __builtin_fmaf(o.w, q.ron[0], __builtin_fmaf(-m.w, q.rmn[0], dvn)), bt0 = __builtin_fmaf(o.w, q.rot_[0], __builtin_fmaf(-m.w, q.rmt[0], dvt));
-    const float a_n0t0 = __builtin_fmaf(q.rmn[0], q.wmt[0], q.ron[0] * q.wot[0]);
-    const bool both = q.npw > 1;  // (wave-uniform; slot 1 holds nothing otherwise)
-    float bn1 = 0.f, bt1 = 0.f, a_n1t1 = 0.f, a_n0n1 = 0.f, a_t0t1 = 0.f, a_n0t1 = 0.f, a_t0n1 = 0.f, ikn1 = 0.f, ikt1 = 0.f, bias1 = 0.f;
-    if (both) {
-        bn1 = __builtin_fmaf(o.w, q.ron[1], __builtin_fmaf(-m.w, q.rmn[1], dvn)); bt1 = __builtin_fmaf(o.w, q.rot_[1], __builtin_fmaf(-m.w, q.rmt[1], dvt));
-        a_n1t1 = __builtin_fmaf(q.rmn[1], q.wmt[1], q.ron[1] * q.wot[1]);
-        a_n0n1 = __builtin_fmaf(q.rmn[0], q.wmn[1], __builtin_fmaf(q.ron[0], q.won[1], imm));
-        a_t0t1 = __builtin_fmaf(q.rmt[0], q.wmt[1], __builtin_fmaf(q.rot_[0], q.wot[1], imm));
-        a_n0t1 = __builtin_fmaf(q.rmn[0], q.wmt[1], q.ron[0] * q.wot[1]); a_t0n1 = __builtin_fmaf(q.rmt[0], q.wmn[1], q.rot_[0] * q.won[1]);
-        ikn1 = two ? q.inv_kn[1] : 0.f; ikt1 = two ? q.inv_kt[1] : 0.f;  // an env with one point: its second row stays at zero
-        bias1 = q.bias[1];
-    }
-    float jn0 = 0.f, jt0 = 0.f, jn1 = 0.f, jt1 = 0.f;
-    for (int it = 0; it < 4; ++it) {
-        float r = bn0 + a_n0t0 * jt0;
-        if (both) r = __builtin_fmaf(a_n0t1, jt1, __builtin_fmaf(a_n0n1, jn1, r));
-        jn0 = __builtin_fmaxf((q.bias[0] - r) * q.inv_kn[0], 0.f);
-        r = __builtin_fmaf(a_n0t0, jn0, bt0);
-        if (both) r = __builtin_fmaf(a_t0t1, jt1, __builtin_fmaf(a_t0n1, jn1, r));
-        float lim = Q.mu * jn0;
-        jt0 = __builtin_fminf(__builtin_fmaxf(-r * q.inv_kt[0], -lim), lim);
-        if (both) {
-            r = __builtin_fmaf(a_n1t1, jt1, __builtin_fmaf(a_t0n1, jt0, __builtin_fmaf(a_n0n1, jn0, bn1)));
-            jn1 = __builtin_fmaxf((bias1 - r) * ikn1, 0.f);
-            r = __builtin_fmaf(a_n1t1, jn1, __builtin_fmaf(a_t0t1, jt0, __builtin_fmaf(a_n0t1, jn0, bt1)));
-            lim = Q.mu * jn1;
-            jt1 = __builtin_fminf(__builtin_fmaxf(-r * ikt1, -lim), lim);
-        }
-    }
-    if (q.np == 0) { jn0 = 0.f; jt0 = 0.f; }  // (an env without contact in a wavefront with one)
-    const float jn = jn0 + jn1, jt = jt0 + jt1;
-    const float px = __builtin_fmaf(jn, nx, -(jt * ny)), py = __builtin_fmaf(jn, ny, jt * nx);  // summed impulse on the object; t = (-ny, nx)
-    m.vx = __builtin_fmaf(-px, Q.inv_mm, m.vx); m.vy = __builtin_fmaf(-py, Q.inv_mm, m.vy);
-    o.vx = __builtin_fmaf(px, Q.inv_mo, o.vx); o.vy = __builtin_fmaf(py, Q.inv_mo, o.vy);
-    float dwm = __builtin_fmaf(jn0, q.wmn[0], jt0 * q.wmt[0]), dwo = __builtin_fmaf(jn0, q.won[0], jt0 * q.wot[0]);
-    if (both) {  // (slot 1 holds nothing in a wavefront whose envs all have one point)
-        dwm = __builtin_fmaf(jn1, q.wmn[1], __builtin_fmaf(jt1, q.wmt[1], dwm));
-        dwo = __builtin_fmaf(jn1, q.won[1], __builtin_fmaf(jt1, q.wot[1], dwo));
-    }
-    m.w -= dwm; o.w += dwo;
+// the row velocities of a pair from the bodies: relative velocity of the object against the mover along n at the two points, along t
+// at the friction row
+template <typename RT>
+__device__ __forceinline__ void p3_row_velocities(const P3Pair<RT> &q, const Body<RT> &m, const Body<RT> &o, RT &vn0, RT &vn1, RT &vt) {
+    const RT dvx = o.vx - m.vx, dvy = o.vy - m.vy;
+    const RT dvn = fma_(dvx, q.nx, dvy * q.ny), dvt = fma_(dvy, q.nx, -(dvx * q.ny));
+    vn0 = fma_(o.w, q.ron0, fma_(-m.w, q.rmn0, dvn)); vn1 = fma_(o.w, q.ron1, fma_(-m.w, q.rmn1, dvn));
+    vt = fma_(o.w, q.rot_, fma_(-m.w, q.rmt, dvt));
 }
 
-// 3b. one visit of a pair's points in a sweep, on the body velocities (any number of points, any number of pairs in contact);
-// `mine`: the lane takes part (pair lanes: only the lanes of the pair whose turn it is)
-__device__ __forceinline__ void fast_velocity_rows(const PushCst<float> &Q, Body<float> &m, Body<float> &o, FastPair &q, bool mine = true) {
-    const float nx = q.nx, ny = q.ny;
-    const float nmx = nx * Q.inv_mm, nmy = ny * Q.inv_mm, nox = nx * Q.inv_mo, noy = ny * Q.inv_mo;
-#pragma unroll
-    for (int k = 0; k < PUSH_SLOTS; ++k) {
-        if (k >= q.npw) break;
-        if ((k < q.np) & mine) {
-            float dvx = o.vx - m.vx, dvy = o.vy - m.vy;
-            const float vn = __builtin_fmaf(dvx, nx, __builtin_fmaf(dvy, ny, __builtin_fmaf(o.w, q.ron[k], -(m.w * q.rmn[k]))));
-            const float jn_new = __builtin_fmaxf(__builtin_fmaf(q.bias[k] - vn, q.inv_kn[k], q.jn[k]), 0.f);
-            const float dj = jn_new - q.jn[k];
-            q.jn[k] = jn_new;
-            m.vx = __builtin_fmaf(-dj, nmx, m.vx); m.vy = __builtin_fmaf(-dj, nmy, m.vy); m.w = __builtin_fmaf(-dj, q.wmn[k], m.w);
-            o.vx = __builtin_fmaf(dj, nox, o.vx); o.vy = __builtin_fmaf(dj, noy, o.vy); o.w = __builtin_fmaf(dj, q.won[k], o.w);
-            dvx = o.vx - m.vx; dvy = o.vy - m.vy;
-            const float vt = __builtin_fmaf(dvy, nx, __builtin_fmaf(-dvx, ny, __builtin_fmaf(o.w, q.rot_[k], -(m.w * q.rmt[k]))));
-            const float lim = Q.mu * jn_new;
-            const float jt_new = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-vt, q.inv_kt[k], q.jt[k]), -lim), lim);
-            const float djt = jt_new - q.jt[k];
-            q.jt[k] = jt_new;
-            // t = (-ny, nx)
-            m.vx = __builtin_fmaf(djt, nmy, m.vx); m.vy = __builtin_fmaf(-djt, nmx, m.vy); m.w = __builtin_fmaf(-djt, q.wmt[k], m.w);
-            o.vx = __builtin_fmaf(-djt, noy, o.vx); o.vy = __builtin_fmaf(djt, nox, o.vy); o.w = __builtin_fmaf(djt, q.wot[k], o.w);
-        }
-    }
+// 3. one visit of a pair: the 2 x 2 normal block exactly (A l + b >= 0, l >= 0, complementary: A is symmetric positive definite, exactly
+// one active set is consistent) with the friction impulse held, then the friction impulse for the new normals. (vn0, vn1, vt) = the row
+// velocities WITHOUT this pair's own impulses.
+template <typename RT> __device__ __forceinline__ void p3_visit(const PushCst<RT> &Q, P3Pair<RT> &q, RT vn0, RT vn1, RT vt) {
+    const RT b0 = fma_(q.ant0, q.jt, vn0 - q.bias0), b1 = fma_(q.ant1, q.jt, vn1 - q.bias1);
+    const bool two = q.np == 2;
+    const RT s0 = max_(-b0 * q.i00, (RT)0);  // only row 0 active
+    const RT x0 = fma_(q.a01, b1, -(q.a11 * b0)) * q.idet, x1 = fma_(q.a01, b0, -(q.a00 * b1)) * q.idet;  // both rows active
+    const RT s1 = max_(-b1 * q.i11, (RT)0);  // only row 1 active
+    const bool both = two & (x0 >= (RT)0) & (x1 >= (RT)0);
+    const bool first = !both & (!two | (fma_(q.a01, s0, b1) >= (RT)0));
+    q.l0 = both ? x0 : first ? s0 : (RT)0;
+    q.l1 = both ? x1 : first ? (RT)0 : s1;
+    const RT lim = Q.mu * (q.l0 + q.l1);
+    const RT r = fma_(q.ant1, q.l1, fma_(q.ant0, q.l0, vt));
+    q.jt = min_(max_(-r * q.itt, -lim), lim);
 }
 
-template <int NM>
-__device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float dt, Body<float> (&mv)[NM], Body<float> &o, const R2<float> (&u)[NM],
-                                                const R2<float> (&rel0)[NM]) {
+// the bodies take the impulses (d0, d1, djt) of a pair's rows; a lane whose pair has no contact takes nothing
+template <typename RT>
+__device__ __forceinline__ void p3_apply(const PushCst<RT> &Q, const P3Pair<RT> &q, Body<RT> &m, Body<RT> &o, RT d0, RT d1, RT djt, bool mine) {
+    d0 = mine ? d0 : (RT)0; d1 = mine ? d1 : (RT)0; djt = mine ? djt : (RT)0;
+    const RT djn = d0 + d1;
+    const RT px = fma_(djn, q.nx, -(djt * q.ny)), py = fma_(djn, q.ny, djt * q.nx);  // impulse on the object; t = (-ny, nx)
+    m.vx = fma_(-px, Q.inv_mm, m.vx); m.vy = fma_(-py, Q.inv_mm, m.vy);
+    o.vx = fma_(px, Q.inv_mo, o.vx); o.vy = fma_(py, Q.inv_mo, o.vy);
+    m.w -= fma_(d1, q.rmn1, fma_(d0, q.rmn0, djt * q.rmt)) * Q.inv_Im;
+    o.w += fma_(d1, q.ron1, fma_(d0, q.ron0, djt * q.rot_)) * Q.inv_Io;
+}
+
+// one pair alone (one mover; or pair lanes when the partner's pair does not touch): both visits on the impulses -- the row velocities are
+// affine in them -- and the bodies take the result once
+template <typename RT> __device__ __forceinline__ void p3_solve_alone(const PushCst<RT> &Q, P3Pair<RT> &q, Body<RT> &m, Body<RT> &o) {
+    RT vn0, vn1, vt;
+    p3_row_velocities(q, m, o, vn0, vn1, vt);
+    p3_visit(Q, q, vn0, vn1, vt);
+    p3_visit(Q, q, vn0, vn1, vt);
+    p3_apply(Q, q, m, o, q.l0, q.l1, q.jt, q.np > 0);
+}
+
+// one visit of a pair among several: the rows' velocities now, minus this pair's own impulses so far; the bodies take the change
+template <typename RT> __device__ __forceinline__ void p3_visit_bodies(const PushCst<RT> &Q, P3Pair<RT> &q, Body<RT> &m, Body<RT> &o, bool mine) {
+    RT vn0, vn1, vt;
+    p3_row_velocities(q, m, o, vn0, vn1, vt);
+    vn0 -= fma_(q.ant0, q.jt, fma_(q.a01, q.l1, q.a00 * q.l0));
+    vn1 -= fma_(q.ant1, q.jt, fma_(q.a11, q.l1, q.a01 * q.l0));
+    vt -= fma_(q.att, q.jt, fma_(q.ant1, q.l1, q.ant0 * q.l0));
+    const RT l0o = q.l0, l1o = q.l1, jto = q.jt;
+    p3_visit(Q, q, vn0, vn1, vt);
+    p3_apply(Q, q, m, o, q.l0 - l0o, q.l1 - l1o, q.jt - jto, mine & (q.np > 0));
+    if (!(mine & (q.np > 0))) { q.l0 = l0o; q.l1 = l1o; q.jt = jto; }
+}
+
+// one control cycle of the NM movers and the object. rel0 (float builds): object - mover at the start of the step, formed in double --
+// the bodies' x, y are then DISPLACEMENTS since the start of the step (a manifold changes discretely wherever a rounding error decides;
+// summing 1e-3-sized increments onto 0.4 m positions in float put 3e-8 m into every cycle); the double builds pass zeros and absolute
+// positions.
+template <typename RT, int NM>
+__device__ __forceinline__ void push_cycle3(const PushCst<RT> &Q, RT dt, Body<RT> (&mv)[NM], Body<RT> &o, const R2<RT> (&u)[NM], const R2<RT> (&rel0)[NM]) {
 #pragma unroll
-    for (int i = 0; i < NM; ++i) fast_forces_mover(Q, dt, mv[i], u[i]);
-    fast_forces_object(Q, o);
-    FastPair pr[NM];
-    bool any_contact = false;
-    float so = 0.f, co = 1.f;
-    bool have_o = false;
-    const float imm = Q.inv_mm + Q.inv_mo, inv_tc = __builtin_amdgcn_rcpf(Q.tc);
+    for (int i = 0; i < NM; ++i) p3_forces_mover(Q, dt, mv[i], u[i]);
+    p3_forces_object(Q, o);
+    P3Pair<RT> pr[NM];
+    bool any = false;
 #pragma unroll
-    for (int i = 0; i < NM; ++i) any_contact |= fast_pair_geometry(Q, mv[i], o, rel0[i], so, co, have_o, imm, inv_tc, pr[i]);
-    // 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points
-    bool in_impulse_space = false;
-    if constexpr (NM == 1) {
-        in_impulse_space = any_contact & (pr[0].npw <= 2);
-        if (in_impulse_space) fast_impulse_solve(Q, imm, mv[0], o, pr[0]);
-    } else {
-        // Two movers: the sweeps visit mover 0's points, then mover 1's -- and an env in which only ONE of the two pairs touches has an
-        // empty half in every sweep: the one-pair solve above is the same computation. It applies when no env of the wavefront has both
-        // pairs in contact (with 4 envs per wavefront at 4 096 envs: practically always). Which pair is per lane: operands selected, the
-        // mover's velocity written back to the selected mover. (A pair whose block was skipped, or whose second slot was never filled,
-        // holds nothing: zeros are selected there.)
-        const bool ran0 = pr[0].npw > 0, ran1 = pr[NM - 1].npw > 0;  // (wave-uniform)
-        const int npw = pr[0].npw > pr[NM - 1].npw ? pr[0].npw : pr[NM - 1].npw;
-        in_impulse_space = any_contact & (npw <= 2) & (__ballot((pr[0].np > 0) & (pr[NM - 1].np > 0)) == 0ull);
-        if (in_impulse_space) {
-            if (ran0 & !ran1) fast_impulse_solve(Q, imm, mv[0], o, pr[0]);
-            else if (ran1 & !ran0) fast_impulse_solve(Q, imm, mv[NM - 1], o, pr[NM - 1]);
-            else {
-                const FastPair &a = pr[0], &b = pr[NM - 1];
-                const bool sel = b.np > 0;  // this env's touching pair is mover 1's (neither touches: pair 0, np = 0, nothing happens)
-                const bool a1 = a.npw > 1, b1 = b.npw > 1;
-                FastPair q;
-                q.np = sel ? b.np : a.np; q.npw = npw; q.nx = sel ? b.nx : a.nx; q.ny = sel ? b.ny : a.ny;
-#define GPR_SEL0(f) q.f[0] = sel ? b.f[0] : a.f[0]
-#define GPR_SEL1(f) q.f[1] = sel ? (b1 ? b.f[1] : 0.f) : (a1 ? a.f[1] : 0.f)
-                GPR_SEL0(rmn); GPR_SEL0(ron); GPR_SEL0(rmt); GPR_SEL0(rot_); GPR_SEL0(wmn); GPR_SEL0(won); GPR_SEL0(wmt); GPR_SEL0(wot);
-                GPR_SEL0(inv_kn); GPR_SEL0(inv_kt); GPR_SEL0(bias);
-                GPR_SEL1(rmn); GPR_SEL1(ron); GPR_SEL1(rmt); GPR_SEL1(rot_); GPR_SEL1(wmn); GPR_SEL1(won); GPR_SEL1(wmt); GPR_SEL1(wot);
-                GPR_SEL1(inv_kn); GPR_SEL1(inv_kt); GPR_SEL1(bias);
-#undef GPR_SEL0
-#undef GPR_SEL1
-                Body<float> m = mv[0];
-                m.vx = sel ? mv[NM - 1].vx : mv[0].vx; m.vy = sel ? mv[NM - 1].vy : mv[0].vy; m.w = sel ? mv[NM - 1].w : mv[0].w;
-                fast_impulse_solve(Q, imm, m, o, q);
-                mv[0].vx = sel ? mv[0].vx : m.vx; mv[0].vy = sel ? mv[0].vy : m.vy; mv[0].w = sel ? mv[0].w : m.w;
-                mv[NM - 1].vx = sel ? m.vx : mv[NM - 1].vx; mv[NM - 1].vy = sel ? m.vy : mv[NM - 1].vy; mv[NM - 1].w = sel ? m.w : mv[NM - 1].w;
+    for (int i = 0; i < NM; ++i) {
+        RT dx = o.x - mv[i].x, dy = o.y - mv[i].y;
+        if constexpr (!Math<RT>::literal) { dx = rel0[i].x + dx; dy = rel0[i].y + dy; }
+        any |= p3_geometry(Q, dt, mv[i], o, dx, dy, pr[i]);
+    }
+    if (any) {  // (wave-uniform) block Gauss-Seidel on the cycle's total impulses: two visits per pair, pair 0, pair 1, pair 0, pair 1
+        if constexpr (NM == 1) {
+            p3_solve_alone(Q, pr[0], mv[0], o);
+        } else {
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int i = 0; i < NM; ++i) p3_visit_bodies(Q, pr[i], mv[i], o, true);
             }
         }
     }
-    if (in_impulse_space) {
-    } else if (any_contact) {  // (wave-uniform)
-        for (int it = 0; it < 4; ++it) {
+    // positions with the new velocities
 #pragma unroll
-            for (int i = 0; i < NM; ++i) fast_velocity_rows(Q, mv[i], o, pr[i]);
-        }
-    }
-    // 4. positions with the new velocities
+    for (int i = 0; i < NM; ++i) { Body<RT> &m = mv[i]; m.x = fma_(dt, m.vx, m.x); m.y = fma_(dt, m.vy, m.y); m.th = fma_(dt, m.w, m.th); }
+    o.x = fma_(dt, o.vx, o.x); o.y = fma_(dt, o.vy, o.y); o.th = fma_(dt, o.w, o.th);
+}
+template <typename RT, int NM>
+__device__ __forceinline__ void push_cycle(const PushCst<RT> &Q, RT dt, Body<RT> (&mv)[NM], Body<RT> &o, const R2<RT> (&u)[NM]) {
+    R2<RT> none[NM];
 #pragma unroll
-    for (int i = 0; i < NM; ++i) { Body<float> &m = mv[i]; m.x = __builtin_fmaf(dt, m.vx, m.x); m.y = __builtin_fmaf(dt, m.vy, m.y); m.th = __builtin_fmaf(dt, m.w, m.th); }
-    o.x = __builtin_fmaf(dt, o.vx, o.x); o.y = __builtin_fmaf(dt, o.vy, o.y); o.th = __builtin_fmaf(dt, o.w, o.th);
+    for (int i = 0; i < NM; ++i) none[i] = R2<RT>{(RT)0, (RT)0};
+    push_cycle3<RT, NM>(Q, dt, mv, o, u, none);
+}
+template <int NM>
+__device__ __forceinline__ void push_cycle_fast(const PushCst<float> &Q, float dt, Body<float> (&mv)[NM], Body<float> &o, const R2<float> (&u)[NM],
+                                                const R2<float> (&rel0)[NM]) {
+    push_cycle3<float, NM>(Q, dt, mv, o, u, rel0);
 }
 
 // the value the other lane of this lane's couple holds (lanes 2k, 2k + 1): quad_perm [1,0,3,2]
 __device__ __forceinline__ uint32_t partner_u32(uint32_t v) { return rot_u32<2, 1>(v); }
 template <typename RT> __device__ __forceinline__ RT partner(RT v) { return rot<2, 1>(v); }
 
-// TWO MOVERS, ONE LANE PER PAIR (k_push<..., PAIR = true>). The two pairs' geometry blocks (~250 instructions each) are where a two-mover
-// cycle spends its time, and in one lane they run one after the other. Here an env's lanes come in couples: the even lane owns mover 0
-// and the pair (mover 0, object), the odd lane mover 1 and its pair; both carry the object. A cycle is then as long as the ONE-mover
-// cycle plus the exchange: the object's new velocity goes from the lane whose pair touched to its partner (three quad_perm moves).
-// Arithmetic and its order are those of push_cycle_fast<2>: with one pair in contact the one-pair impulse-space solve in that pair's lane;
-// otherwise (some env of the wavefront has both pairs touching, or more than two points) the velocity sweeps, mover 0's points, then
-// mover 1's, the object's velocity handed over after every visit.
+// TWO MOVERS, ONE LANE PER PAIR (k_push<..., PAIR = true>, float). The pairs' geometry blocks are where a two-mover cycle spends its time,
+// and in one lane they run one after the other. Here an env's lanes come in couples: the even lane owns mover 0 and the pair (mover 0,
+// object), the odd lane mover 1 and its pair; both carry the object. Arithmetic and order are those of push_cycle3<float, 2>: the visits
+// pair 0, pair 1, pair 0, pair 1 on the bodies, the object's velocity handed from the lane that just visited to its partner (three
+// quad_perm moves per visit). An env in which only ONE pair touches -- the usual push -- would run empty visits for the other: when no env
+// of the wavefront has both pairs in contact the touching pair's lane solves alone on the impulses (the same two visits: with the other
+// pair idle nothing changes the rows' free velocities in between) and hands the object over once.
 __device__ __forceinline__ void push_cycle_pair(const PushCst<float> &Q, float dt, Body<float> &m, Body<float> &o, R2<float> u, R2<float> rel0, bool second) {
-    fast_forces_mover(Q, dt, m, u);
-    fast_forces_object(Q, o);
-    FastPair q;
-    float so = 0.f, co = 1.f;
-    bool have_o = false;
-    const float imm = Q.inv_mm + Q.inv_mo, inv_tc = __builtin_amdgcn_rcpf(Q.tc);
-    if (fast_pair_geometry(Q, m, o, rel0, so, co, have_o, imm, inv_tc, q)) {  // (wave-uniform: some lane of either pair touches)
-        const bool other = partner_u32((uint32_t)q.np) != 0u;                // the partner's pair touches
+    p3_forces_mover(Q, dt, m, u);
+    p3_forces_object(Q, o);
+    P3Pair<float> q;
+    if (p3_geometry(Q, dt, m, o, rel0.x + (o.x - m.x), rel0.y + (o.y - m.y), q)) {  // (wave-uniform: some lane of either pair touches)
+        const bool other = partner_u32((uint32_t)q.np) != 0u;                   // the partner's pair touches
         auto from_partner = [&](bool take) {
             const float vx = partner(o.vx), vy = partner(o.vy), w = partner(o.w);
             o.vx = take ? vx : o.vx; o.vy = take ? vy : o.vy; o.w = take ? w : o.w;
         };
-        if ((q.npw <= 2) & (__ballot((q.np > 0) & other) == 0ull)) {
-            fast_impulse_solve(Q, imm, m, o, q);
+        if (__ballot((q.np > 0) & other) == 0ull) {
+            p3_solve_alone(Q, q, m, o);
             from_partner((q.np == 0) & other);
         } else {
-            for (int it = 0; it < 4; ++it) {
-                fast_velocity_rows(Q, m, o, q, !second);
+            for (int it = 0; it < 2; ++it) {
+                p3_visit_bodies(Q, q, m, o, !second);
                 from_partner(second);
-                fast_velocity_rows(Q, m, o, q, second);
+                p3_visit_bodies(Q, q, m, o, second);
                 from_partner(!second);
             }
         }
     }
-    m.x = __builtin_fmaf(dt, m.vx, m.x); m.y = __builtin_fmaf(dt, m.vy, m.y); m.th = __builtin_fmaf(dt, m.w, m.th);
-    o.x = __builtin_fmaf(dt, o.vx, o.x); o.y = __builtin_fmaf(dt, o.vy, o.y); o.th = __builtin_fmaf(dt, o.w, o.th);
+    m.x = fma_(dt, m.vx, m.x); m.y = fma_(dt, m.vy, m.y); m.th = fma_(dt, m.w, m.th);
+    o.x = fma_(dt, o.vx, o.x); o.y = fma_(dt, o.vy, o.y); o.th = fma_(dt, o.w, o.th);
 }
 
 template <typename RT, int NM> struct PushObs {
@@ -837,7 +676,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                     qacc[i] = clamp_dyn<RT>(vn, C.v_max, a[i], C.dt, C.inv_dt, vnext);
                 }
             }
-            // mj_step (BE:1882): engine model gpr-push-v2. An env that has collided stands still (BE:1904-1905): its lanes sit the
+            // mj_step (BE:1882): engine model gpr-push-v3. An env that has collided stands still (BE:1904-1905): its lanes sit the
             // cycle out (the votes inside push_cycle then only count the envs that still move, as they should)
             if (!frozen) {
                 if constexpr (Math<RT>::literal) push_cycle<RT, NM>(Q, C.dt, m, o, qacc);

@@ -873,27 +873,155 @@ int32_t gpro_planning_step_mt(const gpro_env_cfg *cfg, int64_t num_envs, uint64_
 
 /* ======================================================================================================
  * BenchmarkPushingEnv (PU = envs/manipulation/benchmark_pushing_env.py). See gpr_oracle.h for what is pinned and what is
- * the engine's own contact model "gpr-push-v1".
+ * the engine's own contact model "gpr-push-v3".
  * ==================================================================================================== */
 typedef struct { double x, y, th, vx, vy, w; } body2;
 
-static double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
 
-/* One control cycle of nm (1 or 2) movers and the object, model "gpr-push-v2". u[i] = commanded acceleration of mover i (world
- * x,y). Semi-implicit Euler: velocities first (external forces, then contact impulses), then positions with the new velocities.
- * Contacts: mover i <-> object for every mover (the movers do not touch each other: coming within their collision circles
- * ends the episode, as in the planning env). Per pair: broad phase on the circumradii, separating-axis test over the 4 face
- * normals, at most GPRO_PUSH_SLOTS contact points (the first vertices, in the fixed order object vertices 0..3 then mover
- * vertices 0..3, that lie inside the other box), effective masses inverted once; then 4 sweeps of sequential impulses over
- * mover 0's points, mover 1's points. */
-#define GPRO_PUSH_SLOTS 4
+/* ------------------------------------------------------------------------------------------------------------------
+ * Engine contact model "gpr-push-v3" (the engine's own -- the reference hands contact to MuJoCo and no
+ * reference test exercises it: PARITY UNPINNED). One control cycle of nm (1 or 2) movers and the object; u[i] = commanded
+ * acceleration of mover i (world x, y). Semi-implicit Euler: velocities first (external forces, then contact impulses), then
+ * positions with the new velocities. Contacts: mover i <-> object for every mover (the movers do not touch each other: coming within
+ * their collision circles ends the episode, as in the planning env).
+ *
+ * Per (mover, object) pair, in the MOVER's frame:
+ *  - broad phase on the circumscribed circles; separating-axis test over the four face normals in the order mover x, mover y,
+ *    object x, object y, the first smallest overlap wins: the contact normal n (mover -> object) and the REFERENCE box (the one
+ *    that owns the axis); the other box is the INCIDENT one;
+ *  - manifold: the incident box's face that faces the reference box most squarely gives the incident segment (two vertices);
+ *    it is cut to the lateral extent of the reference face (along the segment's own line); an end whose depth below the reference
+ *    face is >= 0 is a contact point: at most TWO points, with their depths. (v2 took the first <= 4 of the eight "vertex inside
+ *    the other box" candidates.)
+ *  - rows: one normal row per point, ONE friction row at the midpoint of the points, bounded by mu (lambda_0 + lambda_1). (v2: a
+ *    friction row per point.)
+ *  - solve: block Gauss-Seidel on the TOTAL impulses of the cycle. A visit of a pair solves its normal block EXACTLY -- the 2 x 2
+ *    linear complementarity problem A l + b >= 0, l >= 0, l (A l + b) = 0 by enumerating the active sets (both, first, second,
+ *    none) -- with the friction impulse held, then sets the friction impulse for the new normals (clamped). Two visits per pair
+ *    and cycle, in the order pair 0, pair 1, pair 0, pair 1. (v2: four sweeps of scalar sequential impulses.) With ONE mover the
+ *    two visits run on the impulses alone (the row velocities are affine in them: b + A lambda), the bodies take the result once.
+ *  - penetration recovery: velocity bias depth / contact_timeconst per normal row, as in v2.
+ *  - contact margin PUSH3_MARGIN (0.1 mm): boxes closer than the margin are "touching", and an end of the incident segment up to the
+ *    margin ABOVE the reference face stays in the manifold as a speculative row -- its bias is depth / dt (negative: the gap may close
+ *    within the cycle, not more). Without it a face-to-face push lost and regained its second point with every micro-radian of relative
+ *    yaw (depths of 1e-7 m), and each loss turned the object by 0.1 rad/s.
+ * fma(a, b, c) marks the fused operations: the device code fuses exactly these (the double builds follow this text operation for
+ * operation; sin / cos come from the device's libm there, hence 1e-9 instead of bit equality in the tests).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define PUSH3_MARGIN 1e-4
 typedef struct {
-    int np;
-    double nx, ny;
-    double rmx[GPRO_PUSH_SLOTS], rmy[GPRO_PUSH_SLOTS], rox[GPRO_PUSH_SLOTS], roy[GPRO_PUSH_SLOTS];
-    double rmn[GPRO_PUSH_SLOTS], ron[GPRO_PUSH_SLOTS], rmt[GPRO_PUSH_SLOTS], rot_[GPRO_PUSH_SLOTS];
-    double inv_kn[GPRO_PUSH_SLOTS], inv_kt[GPRO_PUSH_SLOTS], bias[GPRO_PUSH_SLOTS], jn[GPRO_PUSH_SLOTS], jt[GPRO_PUSH_SLOTS];
-} push_pair;
+    int np;                       /* 0, 1, 2 contact points */
+    double nx, ny;                /* contact normal, mover -> object, world frame */
+    double rmn[2], ron[2];        /* lever arms x n of the two normal rows (mover's, object's) */
+    double rmt, rot_;             /* lever arms x t of the friction row, t = (-ny, nx) */
+    double bias[2];
+    double a00, a01, a11, att, ant0, ant1; /* A = J M^-1 J^T of the three rows */
+    double i00, i11, idet, itt;   /* 1 / a00, 1 / a11, 1 / (a00 a11 - a01^2), 1 / att: formed once per cycle, both visits multiply */
+    double l0, l1, jt;            /* total impulses of the cycle so far */
+} push3_pair;
+
+/* 2 x 2 LCP  A l + b >= 0, l >= 0, complementary; A symmetric positive definite: exactly one active set is consistent */
+static void push3_lcp2(const push3_pair *q, double b0, double b1, double *l0, double *l1) {
+    const int two = q->np == 2;
+    const double s0 = fmax(-b0 * q->i00, 0.0);        /* only row 0 active */
+    const double x0 = fma(q->a01, b1, -(q->a11 * b0)) * q->idet, x1 = fma(q->a01, b0, -(q->a00 * b1)) * q->idet; /* both rows active */
+    const double s1 = fmax(-b1 * q->i11, 0.0);        /* only row 1 active */
+    const int both = two && x0 >= 0.0 && x1 >= 0.0;
+    const int first = !both && (!two || fma(q->a01, s0, b1) >= 0.0);
+    *l0 = both ? x0 : first ? s0 : 0.0;
+    *l1 = both ? x1 : first ? 0.0 : s1;
+}
+
+/* contact geometry of one pair; dx, dy = object centre - mover centre (world). Returns q->np. */
+static int push3_geometry(const gpro_push_params *pp, double dt, const body2 *m, const body2 *o, double dx, double dy, double inv_mm, double inv_mo,
+                          double inv_Im, double inv_Io, push3_pair *q) {
+    const double ax = pp->mover_half[0], ay = pp->mover_half[1], h = pp->object_half;
+    q->np = 0; q->nx = 0.0; q->ny = 0.0; q->l0 = q->l1 = q->jt = 0.0;
+    const double reach = sqrt(ax * ax + ay * ay) + h * sqrt(2.0) + PUSH3_MARGIN, reach2 = reach * reach;
+    if (fma(dx, dx, dy * dy) > reach2) return 0; /* broad phase: the circumscribed circles (+ margin) are apart */
+    const double cm = cos(m->th), sm = sin(m->th), co = cos(o->th), so = sin(o->th);
+    const double c = fma(co, cm, so * sm), s = fma(so, cm, -(co * sm));     /* the object's axes in the mover's frame: (c, s), (-s, c) */
+    const double lx = fma(dx, cm, dy * sm), ly = fma(dy, cm, -(dx * sm));   /* the object's centre in the mover's frame */
+    const double ac = fabs(c), as = fabs(s);
+    const double ro01 = h * (ac + as);
+    const double d2 = fma(lx, c, ly * s), d3 = fma(ly, c, -(lx * s));
+    const double ov0 = (ax + ro01) - fabs(lx), ov1 = (ay + ro01) - fabs(ly);
+    const double ov2 = (fma(ax, ac, ay * as) + h) - fabs(d2), ov3 = (fma(ax, as, ay * ac) + h) - fabs(d3);
+    if (fmin(fmin(ov0, ov1), fmin(ov2, ov3)) < -PUSH3_MARGIN) return 0;
+    int k = 0; double best = ov0;
+    if (ov1 < best) { best = ov1; k = 1; }
+    if (ov2 < best) { best = ov2; k = 2; }
+    if (ov3 < best) { best = ov3; k = 3; }
+    /* everything below in the mover's frame. Reference box: centre (rcx, rcy), outward normal (rnx, rny) towards the incident box, face
+     * tangent (-rny, rnx), half extents en (along the normal) and et (along the face). Incident box: centre (icx, icy), axes (ux, uy) and
+     * (vx, vy) with half extents hu, hv. nlx, nly: the contact normal mover -> object. */
+    double nlx, nly, rcx, rcy, rnx, rny, en, et, icx, icy, ux, uy, vx, vy, hu, hv;
+    if (k < 2) { /* the mover's face is the reference face */
+        nlx = k == 0 ? copysign(1.0, lx) : 0.0; nly = k == 0 ? 0.0 : copysign(1.0, ly);
+        rcx = 0.0; rcy = 0.0; rnx = nlx; rny = nly; en = k == 0 ? ax : ay; et = k == 0 ? ay : ax;
+        icx = lx; icy = ly; ux = c; uy = s; vx = -s; vy = c; hu = h; hv = h;
+    } else {     /* the object's face is the reference face */
+        const double sg = copysign(1.0, k == 2 ? d2 : d3);
+        nlx = sg * (k == 2 ? c : -s); nly = sg * (k == 2 ? s : c);
+        rcx = lx; rcy = ly; rnx = -nlx; rny = -nly; en = h; et = h;
+        icx = 0.0; icy = 0.0; ux = 1.0; uy = 0.0; vx = 0.0; vy = 1.0; hu = ax; hv = ay;
+    }
+    /* incident face: the one whose outward normal is most opposed to the reference normal */
+    const double pu = fma(rnx, ux, rny * uy), pv = fma(rnx, vx, rny * vy);
+    double fx, fy, ex, ey; /* face centre offset from the incident centre, half edge vector */
+    if (fabs(pu) >= fabs(pv)) { const double sgn = -copysign(1.0, pu); fx = sgn * hu * ux; fy = sgn * hu * uy; ex = hv * vx; ey = hv * vy; }
+    else                      { const double sgn = -copysign(1.0, pv); fx = sgn * hv * vx; fy = sgn * hv * vy; ex = hu * ux; ey = hu * uy; }
+    const double bx = (icx + fx) - rcx, by = (icy + fy) - rcy;               /* face centre relative to the reference centre */
+    const double pax = bx - ex, pay = by - ey, pbx = bx + ex, pby = by + ey; /* the incident segment's ends */
+    const double tx = -rny, ty = rnx;
+    const double sa = fma(pax, tx, pay * ty), sb = fma(pbx, tx, pby * ty);   /* lateral coordinates on the reference face */
+    const double da = en - fma(pax, rnx, pay * rny), db = en - fma(pbx, rnx, pby * rny); /* depths below the reference face */
+    if (fmin(sa, sb) > et || fmax(sa, sb) < -et) return 0;                   /* the segment passes the face by */
+    const double inv = 1.0 / (sb - sa);
+    const double ta = (fmin(fmax(sa, -et), et) - sa) * inv, tb = (fmin(fmax(sb, -et), et) - sa) * inv; /* cut to [-et, et] along the segment */
+    double px[2], py[2], dep[2];
+    px[0] = fma(ta, pbx - pax, pax) + rcx; py[0] = fma(ta, pby - pay, pay) + rcy; dep[0] = fma(ta, db - da, da);
+    px[1] = fma(tb, pbx - pax, pax) + rcx; py[1] = fma(tb, pby - pay, pay) + rcy; dep[1] = fma(tb, db - da, da);
+    /* points with depth >= -margin, the deeper one first */
+    const int k0 = dep[1] > dep[0] ? 1 : 0, k1 = 1 - k0;
+    if (dep[k0] < -PUSH3_MARGIN) return 0;
+    int np = dep[k1] >= -PUSH3_MARGIN ? 2 : 1;
+    const double p0x = px[k0], p0y = py[k0], p1x = np == 2 ? px[k1] : p0x, p1y = np == 2 ? py[k1] : p0y;
+    const double d0 = dep[k0], d1 = np == 2 ? dep[k1] : 0.0;
+    /* rows: r x n and r x t are the same in every frame; the mover's lever arm is the point itself, the object's the point - (lx, ly) */
+    const double mxc = 0.5 * (p0x + p1x), myc = 0.5 * (p0y + p1y);           /* friction row: midpoint of the points */
+    q->rmn[0] = fma(p0x, nly, -(p0y * nlx)); q->ron[0] = fma(p0x - lx, nly, -((p0y - ly) * nlx));
+    q->rmn[1] = fma(p1x, nly, -(p1y * nlx)); q->ron[1] = fma(p1x - lx, nly, -((p1y - ly) * nlx));
+    q->rmt = fma(mxc, nlx, myc * nly); q->rot_ = fma(mxc - lx, nlx, (myc - ly) * nly);
+    const double imm = inv_mm + inv_mo;
+    const double wm0 = q->rmn[0] * inv_Im, wo0 = q->ron[0] * inv_Io, wm1 = q->rmn[1] * inv_Im, wo1 = q->ron[1] * inv_Io;
+    const double wmt = q->rmt * inv_Im, wot = q->rot_ * inv_Io;
+    q->a00 = fma(q->rmn[0], wm0, fma(q->ron[0], wo0, imm));
+    q->a11 = fma(q->rmn[1], wm1, fma(q->ron[1], wo1, imm));
+    q->a01 = fma(q->rmn[0], wm1, fma(q->ron[0], wo1, imm));
+    q->att = fma(q->rmt, wmt, fma(q->rot_, wot, imm));
+    q->ant0 = fma(q->rmn[0], wmt, q->ron[0] * wot);
+    q->ant1 = fma(q->rmn[1], wmt, q->ron[1] * wot);
+    /* two points that (nearly) coincide make the block singular: the deeper one stands for both */
+    const double det = fma(q->a00, q->a11, -(q->a01 * q->a01));
+    if (np == 2 && !(det > 1e-4 * (q->a00 * q->a11))) np = 1;
+    q->i00 = 1.0 / q->a00; q->i11 = 1.0 / q->a11; q->idet = 1.0 / det; q->itt = 1.0 / q->att;
+    q->bias[0] = d0 >= 0.0 ? d0 / pp->contact_timeconst : d0 / dt; /* recovery; speculative: the gap may close within the cycle */
+    q->bias[1] = d1 >= 0.0 ? d1 / pp->contact_timeconst : d1 / dt;
+    q->nx = fma(nlx, cm, -(nly * sm)); q->ny = fma(nlx, sm, nly * cm);
+    q->np = np;
+    return np;
+}
+
+/* one visit of a pair: the normal block exactly with the friction impulse held, then the friction impulse; (vn0, vn1, vt) = the row
+ * velocities WITHOUT this pair's own impulses */
+static void push3_visit(const gpro_push_params *pp, push3_pair *q, double vn0, double vn1, double vt) {
+    const double b0 = fma(q->ant0, q->jt, vn0 - q->bias[0]), b1 = fma(q->ant1, q->jt, vn1 - q->bias[1]);
+    push3_lcp2(q, b0, b1, &q->l0, &q->l1);
+    const double lim = pp->friction_contact * (q->l0 + q->l1);
+    const double r = fma(q->ant1, q->l1, fma(q->ant0, q->l0, vt));
+    q->jt = fmin(fmax(-r * q->itt, -lim), lim);
+}
 
 static void push_cycle(const gpro_env_cfg *cfg, const gpro_push_params *pp, int nm, body2 *mv, body2 *o, const double (*u)[2]) {
     const double dt = cfg->dt;
@@ -905,109 +1033,68 @@ static void push_cycle(const gpro_env_cfg *cfg, const gpro_push_params *pp, int 
     const double Kr = pp->rot_stiffness, Dr = 2.0 * sqrt(Kr * pp->mover_mass);
     for (int i = 0; i < nm; ++i) {
         body2 *m = mv + i;
-        m->vx = m->vx + dt * u[i][0];
-        m->vy = m->vy + dt * u[i][1];
-        m->w = (m->w + dt * (Kr * (0.0 - m->th)) * inv_Im) / (1.0 + dt * Dr * inv_Im);
+        m->vx = fma(dt, u[i][0], m->vx);
+        m->vy = fma(dt, u[i][1], m->vy);
+        m->w = fma(-(dt * Kr * inv_Im), m->th, m->w) / (1.0 + dt * Dr * inv_Im);
     }
     /* object: free-joint damping (PU:335, implicit like MuJoCo's Euler integrator), then Coulomb friction with the tile,
      * never reversing the motion */
-    double s = 1.0 / (1.0 + dt * pp->object_damping * inv_mo);
-    o->vx = o->vx * s; o->vy = o->vy * s;
-    o->w = o->w / (1.0 + dt * pp->object_damping * inv_Io);
     {
-        double sp = sqrt(o->vx * o->vx + o->vy * o->vy), dv = pp->friction_tile * pp->gravity * dt;
-        if (sp <= dv) { o->vx = 0.0; o->vy = 0.0; } else { double k = (sp - dv) / sp; o->vx = o->vx * k; o->vy = o->vy * k; }
-        double dw = pp->friction_torsional * pp->object_mass * pp->gravity * inv_Io * dt, aw = fabs(o->w);
-        if (aw <= dw) o->w = 0.0; else o->w = o->w * ((aw - dw) / aw);
+        const double sdl = 1.0 / (1.0 + dt * pp->object_damping * inv_mo);
+        const double vx = o->vx * sdl, vy = o->vy * sdl, w = o->w / (1.0 + dt * pp->object_damping * inv_Io);
+        const double sp = sqrt(fma(vx, vx, vy * vy)), dv = pp->friction_tile * pp->gravity * dt;
+        const double kf = sp > dv ? (sp - dv) / sp : 0.0;
+        o->vx = vx * kf; o->vy = vy * kf;
+        const double dw = pp->friction_torsional * pp->object_mass * pp->gravity * inv_Io * dt, aw = fabs(w);
+        o->w = aw <= dw ? 0.0 : copysign(aw - dw, w);
     }
     /* 2. contact geometry per pair */
-    push_pair pr[2];
-    const double co = cos(o->th), so = sin(o->th);
-    const double reach = sqrt(ax * ax + ay * ay) + h * sqrt(2.0), reach2 = reach * reach;
-    const double sx[4] = {-1, -1, 1, 1}, sy[4] = {-1, 1, 1, -1};
-    for (int i = 0; i < nm; ++i) {
-        const body2 *m = mv + i;
-        push_pair *q = pr + i;
-        q->np = 0; q->nx = 0.0; q->ny = 0.0;
-        const double dx = o->x - m->x, dy = o->y - m->y;
-        if (dx * dx + dy * dy > reach2) continue; /* broad phase: the circumscribed circles are apart */
-        const double cm = cos(m->th), sm = sin(m->th);
-        const double axes[4][2] = {{cm, sm}, {-sm, cm}, {co, so}, {-so, co}};
-        double best = INFINITY, nx = 0.0, ny = 0.0;
-        int touching = 1;
-        for (int k = 0; k < 4; ++k) {
-            const double ex = axes[k][0], ey = axes[k][1];
-            const double rm = ax * fabs(ex * cm + ey * sm) + ay * fabs(-ex * sm + ey * cm);
-            const double ro = h * fabs(ex * co + ey * so) + h * fabs(-ex * so + ey * co);
-            const double d = dx * ex + dy * ey;
-            const double overlap = rm + ro - fabs(d);
-            if (overlap < 0.0) { touching = 0; break; }
-            if (overlap < best) { best = overlap; nx = d < 0.0 ? -ex : ex; ny = d < 0.0 ? -ey : ey; }
-        }
-        if (!touching) continue;
-        /* contact points: object vertices inside the mover, then mover vertices inside the object; depth along n. If the boxes
-         * cross without a vertex inside (rare), one point midway between the centres with the SAT depth. */
-        double cx[GPRO_PUSH_SLOTS], cy[GPRO_PUSH_SLOTS], dep[GPRO_PUSH_SLOTS];
-        int np = 0;
-        const double rm_n = ax * fabs(nx * cm + ny * sm) + ay * fabs(-nx * sm + ny * cm);
-        const double ro_n = h * fabs(nx * co + ny * so) + h * fabs(-nx * so + ny * co);
-        for (int k = 0; k < 4; ++k) { /* object vertex in the mover frame */
-            const double vx = o->x + co * (sx[k] * h) - so * (sy[k] * h), vy = o->y + so * (sx[k] * h) + co * (sy[k] * h);
-            const double lx = (vx - m->x) * cm + (vy - m->y) * sm, ly = -(vx - m->x) * sm + (vy - m->y) * cm;
-            if (fabs(lx) <= ax && fabs(ly) <= ay && np < GPRO_PUSH_SLOTS) {
-                cx[np] = vx; cy[np] = vy; dep[np] = rm_n - ((vx - m->x) * nx + (vy - m->y) * ny); ++np;
+    push3_pair pr[2];
+    int any = 0;
+    for (int i = 0; i < nm; ++i) any |= push3_geometry(pp, dt, mv + i, o, o->x - mv[i].x, o->y - mv[i].y, inv_mm, inv_mo, inv_Im, inv_Io, pr + i) > 0;
+    /* 3. block Gauss-Seidel on the cycle's total impulses: two visits per pair, pair 0, pair 1, pair 0, pair 1 */
+    if (any && nm == 1) { /* one pair: both visits on the impulses alone, the bodies take the result once */
+        push3_pair *q = pr;
+        body2 *m = mv;
+        const double dvx = o->vx - m->vx, dvy = o->vy - m->vy;
+        const double dvn = fma(dvx, q->nx, dvy * q->ny), dvt = fma(dvy, q->nx, -(dvx * q->ny));
+        const double vn0 = fma(o->w, q->ron[0], fma(-m->w, q->rmn[0], dvn)), vn1 = fma(o->w, q->ron[1], fma(-m->w, q->rmn[1], dvn));
+        const double vt = fma(o->w, q->rot_, fma(-m->w, q->rmt, dvt));
+        push3_visit(pp, q, vn0, vn1, vt);
+        push3_visit(pp, q, vn0, vn1, vt);
+        const double jn = q->l0 + q->l1;
+        const double px = fma(jn, q->nx, -(q->jt * q->ny)), py = fma(jn, q->ny, q->jt * q->nx); /* impulse on the object; t = (-ny, nx) */
+        m->vx = fma(-px, inv_mm, m->vx); m->vy = fma(-py, inv_mm, m->vy);
+        o->vx = fma(px, inv_mo, o->vx); o->vy = fma(py, inv_mo, o->vy);
+        m->w -= fma(q->l1, q->rmn[1], fma(q->l0, q->rmn[0], q->jt * q->rmt)) * inv_Im;
+        o->w += fma(q->l1, q->ron[1], fma(q->l0, q->ron[0], q->jt * q->rot_)) * inv_Io;
+    } else if (any) {
+        for (int it = 0; it < 2; ++it)
+            for (int i = 0; i < nm; ++i) {
+                push3_pair *q = pr + i;
+                body2 *m = mv + i;
+                if (q->np == 0) continue;
+                const double dvx = o->vx - m->vx, dvy = o->vy - m->vy;
+                const double dvn = fma(dvx, q->nx, dvy * q->ny), dvt = fma(dvy, q->nx, -(dvx * q->ny));
+                /* the rows' velocities now, then without this pair's own impulses */
+                double vn0 = fma(o->w, q->ron[0], fma(-m->w, q->rmn[0], dvn)), vn1 = fma(o->w, q->ron[1], fma(-m->w, q->rmn[1], dvn));
+                double vt = fma(o->w, q->rot_, fma(-m->w, q->rmt, dvt));
+                vn0 -= fma(q->ant0, q->jt, fma(q->a01, q->l1, q->a00 * q->l0));
+                vn1 -= fma(q->ant1, q->jt, fma(q->a11, q->l1, q->a01 * q->l0));
+                vt -= fma(q->att, q->jt, fma(q->ant1, q->l1, q->ant0 * q->l0));
+                const double l0o = q->l0, l1o = q->l1, jto = q->jt;
+                push3_visit(pp, q, vn0, vn1, vt);
+                const double d0 = q->l0 - l0o, d1 = q->l1 - l1o, djt = q->jt - jto, djn = d0 + d1;
+                const double px = fma(djn, q->nx, -(djt * q->ny)), py = fma(djn, q->ny, djt * q->nx);
+                m->vx = fma(-px, inv_mm, m->vx); m->vy = fma(-py, inv_mm, m->vy);
+                o->vx = fma(px, inv_mo, o->vx); o->vy = fma(py, inv_mo, o->vy);
+                m->w -= fma(d1, q->rmn[1], fma(d0, q->rmn[0], djt * q->rmt)) * inv_Im;
+                o->w += fma(d1, q->ron[1], fma(d0, q->ron[0], djt * q->rot_)) * inv_Io;
             }
-        }
-        for (int k = 0; k < 4; ++k) { /* mover vertex in the object frame */
-            const double vx = m->x + cm * (sx[k] * ax) - sm * (sy[k] * ay), vy = m->y + sm * (sx[k] * ax) + cm * (sy[k] * ay);
-            const double lx = (vx - o->x) * co + (vy - o->y) * so, ly = -(vx - o->x) * so + (vy - o->y) * co;
-            if (fabs(lx) <= h && fabs(ly) <= h && np < GPRO_PUSH_SLOTS) {
-                cx[np] = vx; cy[np] = vy; dep[np] = ro_n + ((vx - o->x) * nx + (vy - o->y) * ny); ++np;
-            }
-        }
-        if (np == 0) { cx[0] = m->x + 0.5 * dx; cy[0] = m->y + 0.5 * dy; dep[0] = best; np = 1; }
-        q->np = np; q->nx = nx; q->ny = ny;
-        const double tx = -ny, ty = nx;
-        for (int k = 0; k < np; ++k) {
-            q->rmx[k] = cx[k] - m->x; q->rmy[k] = cy[k] - m->y; q->rox[k] = cx[k] - o->x; q->roy[k] = cy[k] - o->y;
-            q->rmn[k] = cross2(q->rmx[k], q->rmy[k], nx, ny); q->ron[k] = cross2(q->rox[k], q->roy[k], nx, ny);
-            q->rmt[k] = cross2(q->rmx[k], q->rmy[k], tx, ty); q->rot_[k] = cross2(q->rox[k], q->roy[k], tx, ty);
-            q->inv_kn[k] = 1.0 / (inv_mm + inv_mo + q->rmn[k] * q->rmn[k] * inv_Im + q->ron[k] * q->ron[k] * inv_Io);
-            q->inv_kt[k] = 1.0 / (inv_mm + inv_mo + q->rmt[k] * q->rmt[k] * inv_Im + q->rot_[k] * q->rot_[k] * inv_Io);
-            q->bias[k] = (dep[k] > 0.0 ? dep[k] : 0.0) / pp->contact_timeconst; /* penetration recovery velocity */
-            q->jn[k] = 0.0; q->jt[k] = 0.0;
-        }
-    }
-    /* 3. sequential impulses: 4 sweeps over mover 0's points, mover 1's points */
-    const double mu = pp->friction_contact;
-    for (int it = 0; it < 4; ++it) {
-        for (int i = 0; i < nm; ++i) {
-            body2 *m = mv + i;
-            push_pair *q = pr + i;
-            const double nx = q->nx, ny = q->ny, tx = -ny, ty = nx;
-            for (int k = 0; k < q->np; ++k) {
-                const double rmx = q->rmx[k], rmy = q->rmy[k], rox = q->rox[k], roy = q->roy[k];
-                double rvx = (o->vx - o->w * roy) - (m->vx - m->w * rmy), rvy = (o->vy + o->w * rox) - (m->vy + m->w * rmx);
-                double dj = -((rvx * nx + rvy * ny) - q->bias[k]) * q->inv_kn[k];
-                double jn_new = q->jn[k] + dj; if (jn_new < 0.0) jn_new = 0.0;
-                dj = jn_new - q->jn[k]; q->jn[k] = jn_new;
-                m->vx -= dj * nx * inv_mm; m->vy -= dj * ny * inv_mm; m->w -= dj * q->rmn[k] * inv_Im;
-                o->vx += dj * nx * inv_mo; o->vy += dj * ny * inv_mo; o->w += dj * q->ron[k] * inv_Io;
-                /* Coulomb friction at the point */
-                rvx = (o->vx - o->w * roy) - (m->vx - m->w * rmy); rvy = (o->vy + o->w * rox) - (m->vy + m->w * rmx);
-                double djt = -(rvx * tx + rvy * ty) * q->inv_kt[k];
-                double lim = mu * q->jn[k], jt_new = q->jt[k] + djt;
-                if (jt_new > lim) jt_new = lim;
-                if (jt_new < -lim) jt_new = -lim;
-                djt = jt_new - q->jt[k]; q->jt[k] = jt_new;
-                m->vx -= djt * tx * inv_mm; m->vy -= djt * ty * inv_mm; m->w -= djt * q->rmt[k] * inv_Im;
-                o->vx += djt * tx * inv_mo; o->vy += djt * ty * inv_mo; o->w += djt * q->rot_[k] * inv_Io;
-            }
-        }
     }
     /* 4. positions with the new velocities */
-    for (int i = 0; i < nm; ++i) { body2 *m = mv + i; m->x += dt * m->vx; m->y += dt * m->vy; m->th += dt * m->w; }
-    o->x += dt * o->vx; o->y += dt * o->vy; o->th += dt * o->w;
+    for (int i = 0; i < nm; ++i) { body2 *m = mv + i; m->x = fma(dt, m->vx, m->x); m->y = fma(dt, m->vy, m->y); m->th = fma(dt, m->w, m->th); }
+    o->x = fma(dt, o->vx, o->x); o->y = fma(dt, o->vy, o->y); o->th = fma(dt, o->w, o->th);
 }
 
 /* _get_obs (PU:529-576), _get_info (PU:578-607), compute_reward / compute_terminated (PU:457-527); nm movers: the observation
@@ -1193,7 +1280,7 @@ int32_t gpro_pushing_step(const gpro_env_cfg *cfg, const gpro_push_params *pp, i
                 }
                 u[i][0] = ac[0]; u[i][1] = ac[1];
             }
-            push_cycle(cfg, pp, nm, m, &o, (const double (*)[2])u); /* mj_step (BE:1882): engine model gpr-push-v2 */
+            push_cycle(cfg, pp, nm, m, &o, (const double (*)[2])u); /* mj_step (BE:1882): engine model gpr-push-v3 */
             double xy[4], qp[2 * 7];
             for (int i = 0; i < nm; ++i) { xy[2 * i] = m[i].x; xy[2 * i + 1] = m[i].y; }
             noisy_qpos(&c, keys, 3u * (uint32_t)cyc + 1u, nm, xy, cfg->std_noise[0], 1, qp);
