@@ -208,8 +208,13 @@ static __device__ const double *g_normal_tab = nullptr;  // [65536] radius, then
 template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32_t key, uint32_t q) {
     const uint32_t r = rng_draw(key, q);
     const double *tab = g_normal_tab;
+#ifdef GPR_TAB_EXPERIMENT
+    const double rad = tab[(r >> 16) & 8191u];
+    const double2 cs = reinterpret_cast<const double2 *>(tab + 65536)[r & 8191u];
+#else
     const double rad = tab[r >> 16];
     const double2 cs = reinterpret_cast<const double2 *>(tab + 65536)[r & 0xFFFFu];
+#endif
     return R2<double>{rad * cs.x, rad * cs.y};
 }
 

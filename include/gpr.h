@@ -219,8 +219,9 @@ int gpr_agent_views(gpr_env *env, const gpr_step_out *out, void *agent_obs_dev, 
  * Pinned by the reference: mover control and clamping (PU:419-448), observation / reward / terminated / info (PU:457-607), reset
  * sampling (PU:373-417), wall check. NOT pinned ("parity unpinned"): contact dynamics -- the reference delegates them to MuJoCo,
  * which this pipeline cannot run and which no reference test exercises; the kernels integrate the engine's own planar
- * rigid-body model gpr-push-v2: 3-DoF boxes, SAT contact with at most four points per pair, sequential
- * impulses with Coulomb friction, tile friction, joint damping (PU:335), impedance hold of the movers' yaw (PU:261-267). */
+ * rigid-body model gpr-push-v3: 3-DoF boxes; per (mover, object) pair a separating-axis test, a clipped two-point
+ * manifold with a 0.1 mm contact margin, two normal rows solved exactly (2 x 2 LCP) + one friction row, two block Gauss-Seidel visits
+ * per cycle; tile friction, joint damping (PU:335), impedance hold of the movers' yaw (PU:261-267). */
 typedef struct {
     double mover_mass;          /* mover_params['mass'] (BE:230) */
     double mover_half_size[2];  /* mover_params['size'][:2] (BE:250) */
