@@ -86,7 +86,7 @@ def committed_profile(kind: str, kernel: str, envs_per_launch: int):
     """what the committed rocprofv3 PMC passes hold for this kernel at this launch size (profiles/round*_{hbm_traffic,valu}.json: lists
     of records keyed by kernel name and envs per launch). Counters cannot be read from inside this process; None when the profiled
     configuration is not the one being run."""
-    for rnd in (3, 2, 1):
+    for rnd in (4, 3, 2, 1):
         try:
             with open(os.path.join(ROOT, 'profiles', f'round{rnd}_{kind}.json')) as f:
                 d = json.load(f)

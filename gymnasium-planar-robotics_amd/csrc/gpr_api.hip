@@ -189,7 +189,7 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
             m1 = std::max(m1, e.csize[(size_t)2 * i + 1] + e.csize[(size_t)2 * j + 1]);
         }
     c.max_b0sum = (RT)m0; c.max_b1sum = (RT)m1;
-    // noise is bounded (gpr-rng-v1 draws the Box-Muller radius from 16 bits): |reading - truth| <= sigma * R per component.
+    // noise is bounded (gpr-rng-v2 draws the Box-Muller radius from 13 bits): |reading - truth| <= sigma * R per component.
     // The slack covers the rounding of the compared expressions (a few ulp of a coordinate of a few metres).
     const double slack = sizeof(RT) == 8 ? 1e-12 : 1e-5;
     c.band_p = (RT)(g.std_noise[0] * NORMAL_MAX_RADIUS * 1.001 + slack);
@@ -203,21 +203,25 @@ template <typename RT> void fill_cst(const gpr_env &e, Cst<RT> &c) {
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-// gpr-rng-v1 in double: radius and (cos, sin) tables over the 16-bit halves of a draw (gpr_device.h), filled with this host's libm
-// exactly as oracle/gpr_oracle.c:gpro_rng_normal_pair computes them. One set per device, kept for the life of the process.
+// gpr-rng-v2 in double: the radius table over the 13 radius bits of a draw and the (cos, sin) table over one octant of its 16 angle bits
+// (gpr_device.h), filled with this host's libm exactly as oracle/gpr_oracle.c fills its own. One set per device, kept for the life of
+// the process.
 hipError_t ensure_normal_tables() {
     static std::vector<int> ready;
     int dev = 0;
     hipError_t he = hipGetDevice(&dev);
     if (he != hipSuccess) return he;
     for (int d : ready) if (d == dev) return hipSuccess;
-    std::vector<double> h((size_t)3 * 65536);
-    for (uint32_t k = 0; k < 65536u; ++k) {
-        const double u1 = (double)(k + 1u) * (1.0 / 65536.0), u2 = (double)k * (1.0 / 65536.0);
-        h[k] = std::sqrt(-2.0 * std::log(u1));
+    std::vector<double> h((size_t)8192 + 2 * 8193);
+    for (uint32_t i = 0; i < 8192u; ++i) {
+        const double u1 = (double)(i + 1u) * (1.0 / 8192.0);
+        h[i] = std::sqrt(-2.0 * std::log(u1));
+    }
+    for (uint32_t j = 0; j <= 8192u; ++j) {
+        const double u2 = (double)j * (1.0 / 65536.0);
         const double ang = 6.283185307179586476925286766559 * u2;
-        h[(size_t)65536 + 2 * k] = std::cos(ang);
-        h[(size_t)65536 + 2 * k + 1] = std::sin(ang);
+        h[(size_t)8192 + 2 * j] = std::cos(ang);
+        h[(size_t)8192 + 2 * j + 1] = std::sin(ang);
     }
     double *d = nullptr;
     he = hipMalloc(reinterpret_cast<void **>(&d), h.size() * sizeof(double));
@@ -406,7 +410,7 @@ int gpr_streams_overlap(void *stream_a, void *stream_b, int32_t *overlap_out) {
     return GPR_OK;
 }
 
-const char *gpr_version(void) { return "gpr-hip 0.1 (gfx950; rng gpr-rng-v1; one lane per mover)"; }
+const char *gpr_version(void) { return "gpr-hip 0.2 (gfx950; rng gpr-rng-v2; contact gpr-push-v3; one lane per mover)"; }
 
 const char *gpr_last_error(const gpr_env *env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 

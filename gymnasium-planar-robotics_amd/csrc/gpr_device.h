@@ -163,8 +163,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 template <typename RT> __device__ __forceinline__ RT absr(RT v) { return v < (RT)0 ? -v : v; }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// RNG spec "gpr-rng-v1": counter based, 32-bit ops. key = hash(seed, tick, kind, env, mover); draw k = lowbias32(key +
-// (k+1)*golden); normal pair q = Box-Muller on the two 16-bit halves of draw q. Mirrors oracle/gpr_oracle.c (gpro_rng_*).
+// RNG spec "gpr-rng-v2": counter based, 32-bit ops. key = hash(seed, tick, kind, env, mover); draw k = lowbias32(key +
+// (k+1)*golden); normal pair q = Box-Muller on the upper 13 / lower 16 bits of draw q. Mirrors oracle/gpr_oracle.c (gpro_rng_*).
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -187,35 +187,38 @@ __device__ __forceinline__ uint32_t rng_draw(uint32_t key, uint32_t k) { return 
 template <typename RT> __device__ __forceinline__ RT rng_uniform(uint32_t key, uint32_t k) {  // [0,1), 24 bits
     return (RT)(rng_draw(key, k) >> 8) * (RT)(1.0 / 16777216.0);
 }
-// Box-Muller on a 16-bit uniform never returns a radius above sqrt(-2 ln 2^-16): each component of a normal pair is bounded.
-constexpr double NORMAL_MAX_RADIUS = 4.709640090061899;  // sqrt(32 ln 2)
+// gpr-rng-v2 (normal pairs; keys, draws and uniforms are v1's): ONE 32-bit draw per pair, the Box-Muller radius from its upper 13 bits --
+// u1 = (i + 1) / 8192, radius sqrt(-2 ln u1) <= sqrt(26 ln 2): each component of a normal pair is bounded --, the angle 2 pi k / 65536
+// from its lower 16.
+constexpr double NORMAL_MAX_RADIUS = 4.245263256915119;  // sqrt(26 ln 2)
 template <typename RT> __device__ __forceinline__ R2<RT> rng_normal_pair(uint32_t key, uint32_t q);
 template <> __device__ __forceinline__ R2<float> rng_normal_pair<float>(uint32_t key, uint32_t q) {
-    // ONE 32-bit draw per pair: radius from the upper 16 bits, angle from the lower 16 (max radius 4.7 sigma).
     const uint32_t r = rng_draw(key, q);
-    const float a = (float)((r >> 16) + 1u);  // (0, 65536] -> u1 = a * 2^-16
+    const float a = (float)((r >> 19) + 1u);  // (0, 8192] -> u1 = a * 2^-13
     const float u2 = (float)(r & 0xFFFFu) * (1.0f / 65536.0f);
-    // v_log_f32 is log2: -2 ln(u1) = -2 ln2 (log2(a) - 16). v_sin / v_cos take revolutions, so 2*pi*u2 needs no multiply.
-    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * (__builtin_amdgcn_logf(a) - 16.0f));
+    // v_log_f32 is log2: -2 ln(u1) = -2 ln2 (log2(a) - 13). v_sin / v_cos take revolutions, so 2*pi*u2 needs no multiply.
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * (__builtin_amdgcn_logf(a) - 13.0f));
     return R2<float>{rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2)};
 }
-// Double precision: log / sin / cos in double are several hundred instructions per draw (the parity kernels spent half their
-// vector instructions in them), and both arguments take only 65 536 values each. So the radius sqrt(-2 ln((k + 1) / 65536)) and
-// the pair (cos, sin)(2 pi k / 65536) come from two tables in device memory (1.5 MB, L2-resident), filled once per device by
-// gpr_create with the host's libm -- the very values the oracle's libm computes, so the noise is bit-identical to the oracle's.
+// Double precision: log / sin / cos in double are several hundred instructions per draw, and the arguments take few values. So the
+// radius comes from a table of 8 192 doubles and (cos, sin) from a table over ONE OCTANT, (cos, sin)(2 pi j / 65536) for j = 0 .. 8192,
+// unfolded by symmetry -- 192 KB, filled once per device by gpr_create with the host's libm: the very values the oracle's tables hold
+// (oracle/gpr_oracle.c: gpro_rng_normal_pair does the same unfolding), so the noise is bit-identical to the oracle's. (v1's tables
+// covered the whole circle and 16 bits of radius: 1.5 MB, fetched through every XCD's L2 by every launch -- 12 MB of fabric traffic
+// per 16 384-env launch of the f64 kernel, more than the launch's own 9.8 MB.)
 // One translation unit = one instance of this pointer (set through set_normal_table_* of that unit).
-static __device__ const double *g_normal_tab = nullptr;  // [65536] radius, then [65536][2] (cos, sin)
+static __device__ const double *g_normal_tab = nullptr;  // [8192] radius, then [8193][2] (cos, sin) of the first octant
 template <> __device__ __forceinline__ R2<double> rng_normal_pair<double>(uint32_t key, uint32_t q) {
     const uint32_t r = rng_draw(key, q);
     const double *tab = g_normal_tab;
-#ifdef GPR_TAB_EXPERIMENT
-    const double rad = tab[(r >> 16) & 8191u];
-    const double2 cs = reinterpret_cast<const double2 *>(tab + 65536)[r & 8191u];
-#else
-    const double rad = tab[r >> 16];
-    const double2 cs = reinterpret_cast<const double2 *>(tab + 65536)[r & 0xFFFFu];
-#endif
-    return R2<double>{rad * cs.x, rad * cs.y};
+    const double rad = tab[r >> 19];
+    const uint32_t k = r & 0xFFFFu, oct = k >> 13, j = k & 8191u;
+    const double2 t = reinterpret_cast<const double2 *>(tab + 8192)[(oct & 1u) ? 8192u - j : j];  // the octant's own angle, or its mirror image
+    const bool swap = (((oct + 1u) >> 1) & 1u) != 0u;       // octants 1, 2, 5, 6: cos and sin change places
+    double c = swap ? t.y : t.x, s = swap ? t.x : t.y;
+    c = (((oct + 2u) >> 2) & 1u) != 0u ? -c : c;             // octants 2 .. 5: cos < 0
+    s = (oct >> 2) != 0u ? -s : s;                           // octants 4 .. 7: sin < 0
+    return R2<double>{rad * c, rad * s};
 }
 
 __device__ __forceinline__ void diag_add(const KParams &P, int which, uint32_t n) {

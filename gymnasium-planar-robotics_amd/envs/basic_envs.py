@@ -278,7 +278,7 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
     # engine additions with no reference counterpart: resumable random streams, checkpoints, episode counters
     # ------------------------------------------------------------------------------------------------------------
     def get_rng_state(self) -> tuple[int, int]:
-        """(seed, tick) of the handle's counter-based random streams (RNG spec gpr-rng-v1, include/gpr.h)."""
+        """(seed, tick) of the handle's counter-based random streams (RNG spec gpr-rng-v2, include/gpr.h)."""
         seed, tick = C.c_uint64(), C.c_uint64()
         _native.check(self._lib.gpr_get_rng_state(self._handle, C.byref(seed), C.byref(tick)), self._handle)
         return int(seed.value), int(tick.value)

@@ -111,7 +111,7 @@ const char *gpr_last_error(const gpr_env *env);
 int gpr_bind_state(gpr_env *env, const gpr_state *state);
 /* reset(seed=...) part of BE:1789-1791: re-keys every random stream and restarts the call counter */
 int gpr_seed(gpr_env *env, uint64_t seed);
-/* Position of the handle's random streams (RNG spec gpr-rng-v1: every draw is a pure function of seed, call counter `tick`, kind,
+/* Position of the handle's random streams (RNG spec gpr-rng-v2: every draw is a pure function of seed, call counter `tick`, kind,
  * global env id, mover, draw index). Together with the caller-owned gpr_state tensors this is ALL the state of a run: save the
  * pair next to the tensors, restore both into a fresh handle, and the run continues bit for bit (the reference checkpoints
  * nothing; its counterpart is pickling `np_random` / `rng_noise`, BE:182,1789-1791). */
@@ -182,7 +182,7 @@ int gpr_read_diagnostics(gpr_env *env, uint64_t *totals_host /* [2] */, void *hi
  * argument). z is what the reference reports, the distance between the mover's bottom and the tile's top (BE:821-824: body z minus the
  * half height) -- constant in this planar engine, passed by the caller (initial_mover_zpos); the quaternion is the identity (planning
  * env) or the yaw rotation (pushing env); z / roll / pitch rates and accelerations are 0. add_noise: Gaussian noise of std_noise[which]
- * on EVERY component, as BE:828 / 841 / 855 add it, from random stream kind 5 of gpr-rng-v1 (key (seed, call counter, 5, global env id,
+ * on EVERY component, as BE:828 / 841 / 855 add it, from random stream kind 5 of gpr-rng-v2 (key (seed, call counter, 5, global env id,
  * mover), components 2k and 2k+1 = normal pair k); a noisy read advances the call counter. Real type = the handle's storage type. */
 int gpr_get_mover_state(gpr_env *env, int32_t which, int32_t n_sel, const int32_t *mover_idx_dev, double z_report, int32_t add_noise,
                         void *out_dev, void *hip_stream);

@@ -449,13 +449,13 @@ void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achiev
 }
 
 /* ======================================================================================================
- * Engine RNG spec "gpr-rng-v1" (engine-defined; the reference draws from NumPy PCG64 streams, which a GPU engine
+ * Engine RNG spec "gpr-rng-v2" (engine-defined; the reference draws from NumPy PCG64 streams, which a GPU engine
  * can neither reproduce nor needs to: sigma = 1e-5 is 10x below the 1e-4 parity tolerance). Counter-based, 32-bit
  * ops only, order-independent, so the HIP kernels (one LANE per mover) and this oracle (one LOOP per env) produce the
  * same integers:
  *   key  h(seed, tick, kind, env, mover) = lowbias32 absorb chain
  *   draw r(h, k) = lowbias32(h + (k+1)*0x9E3779B9)                 (murmur-style finaliser over a Weyl sequence)
- *   normal pair q = Box-Muller on the two 16-bit halves of draw q; uniform k = upper 24 bits of draw k
+ *   normal pair q = Box-Muller on the upper 13 (radius) / lower 16 (angle) bits of draw q; uniform k = upper 24 bits of draw k
  * ==================================================================================================== */
 static uint32_t mix32(uint32_t x) { /* "lowbias32" integer hash (C. Wellons) */
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -479,15 +479,36 @@ uint32_t gpro_rng_draw(uint32_t key, uint32_t k) { return mix32(key + (k + 1u) *
 
 double gpro_rng_uniform(uint32_t key, uint32_t k) { return (double)(gpro_rng_draw(key, k) >> 8) * (1.0 / 16777216.0); } /* [0,1) */
 
+/* gpr-rng-v2: ONE 32-bit draw per pair; the Box-Muller radius from its upper 13 bits (u1 = (i + 1) / 8192: radius <= sqrt(26 ln 2) =
+ * 4.245 sigma), the angle 2 pi k / 65536 from its lower 16 bits, looked up in a table over the FIRST OCTANT (j = 0 .. 8192) and unfolded
+ * by symmetry -- the engine's double builds read the same two tables (192 KB, filled by the same libm calls on the same host), which is
+ * what makes the noise bit-identical; its float build computes the same quantities with the GPU's log2 / sqrt / sin / cos. */
+static double g_rad_tab[8192], g_trig_tab[8193][2];
+static pthread_once_t g_tab_once = PTHREAD_ONCE_INIT;
+static void fill_normal_tables(void) {
+    for (uint32_t i = 0; i < 8192u; ++i) {
+        const double u1 = (double)(i + 1u) * (1.0 / 8192.0); /* (0,1] */
+        g_rad_tab[i] = sqrt(-2.0 * log(u1));
+    }
+    for (uint32_t j = 0; j <= 8192u; ++j) {
+        const double u2 = (double)j * (1.0 / 65536.0);
+        const double ang = 6.283185307179586476925286766559 * u2;
+        g_trig_tab[j][0] = cos(ang);
+        g_trig_tab[j][1] = sin(ang);
+    }
+}
 void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1) {
-    /* ONE 32-bit draw per pair: radius from the upper 16 bits, angle from the lower 16 (max radius 4.7 sigma) */
-    uint32_t r = gpro_rng_draw(key, q);
-    double u1 = (double)((r >> 16) + 1u) * (1.0 / 65536.0); /* (0,1] */
-    double u2 = (double)(r & 0xFFFFu) * (1.0 / 65536.0);    /* [0,1) */
-    double rad = sqrt(-2.0 * log(u1));
-    double ang = 6.283185307179586476925286766559 * u2;
-    *n0 = rad * cos(ang);
-    *n1 = rad * sin(ang);
+    pthread_once(&g_tab_once, fill_normal_tables);
+    const uint32_t r = gpro_rng_draw(key, q);
+    const double rad = g_rad_tab[r >> 19];
+    const uint32_t k = r & 0xFFFFu, oct = k >> 13, j = k & 8191u;
+    const double *t = g_trig_tab[(oct & 1u) ? 8192u - j : j]; /* the octant's own angle, or its mirror image */
+    const int swap = (int)(((oct + 1u) >> 1) & 1u);            /* octants 1, 2, 5, 6: cos and sin change places */
+    double c = swap ? t[1] : t[0], s = swap ? t[0] : t[1];
+    if (((oct + 2u) >> 2) & 1u) c = -c;                        /* octants 2 .. 5: cos < 0 */
+    if (oct >> 2) s = -s;                                      /* octants 4 .. 7: sin < 0 */
+    *n0 = rad * c;
+    *n1 = rad * s;
 }
 
 enum { KIND_STEP_NOISE = 1, KIND_RESET_START = 2, KIND_RESET_GOAL = 3, KIND_RESET_NOISE = 4, KIND_GETTER_NOISE = 5 };

@@ -93,16 +93,16 @@ void gpro_compute_reward(int64_t batch, int32_t num_movers, const double *achiev
                          const uint8_t *mover_collision, const uint8_t *wall_collision, double threshold_pos,
                          double reward_success, double *reward, uint8_t *terminated, uint8_t *is_success);
 
-/* ---- engine RNG spec "gpr-rng-v1" (engine-defined, counter-based; the reference uses NumPy PCG64 streams) ----------
+/* ---- engine RNG spec "gpr-rng-v2" (engine-defined, counter-based; the reference uses NumPy PCG64 streams) ----------
  * key = hash(seed, tick, kind, env_id, mover); draw k of a key = lowbias32(key + (k+1)*0x9E3779B9);
- * normal pair q = Box-Muller on the two 16-bit halves of draw q; uniform k = top 24 bits of draw k. kinds: 1 step noise, 2 reset starts, 3 reset goals, 4 reset noise. */
+ * normal pair q = Box-Muller on the upper 13 (radius) / lower 16 (angle) bits of draw q; uniform k = top 24 bits of draw k. kinds: 1 step noise, 2 reset starts, 3 reset goals, 4 reset noise. */
 uint32_t gpro_rng_key(uint64_t seed, uint64_t tick, uint32_t kind, uint64_t env_id, uint32_t mover);
 uint32_t gpro_rng_draw(uint32_t key, uint32_t k);
 double gpro_rng_uniform(uint32_t key, uint32_t k);
 void gpro_rng_normal_pair(uint32_t key, uint32_t q, double *n0, double *n1);
 
 /* get_mover_qpos / qvel / qacc (+ _arr) of every env (BE:801-855, 1244-1290): which 0 qpos -> out [E][n_sel][7], 1 qvel / 2 qacc -> [E][n_sel][6].
- * mover_rot nullable [E][2M] (yaw, yaw rate: the pushing env). Noise: stream kind 5 of gpr-rng-v1, components (2k, 2k+1) = normal pair k. */
+ * mover_rot nullable [E][2M] (yaw, yaw rate: the pushing env). Noise: stream kind 5 of gpr-rng-v2, components (2k, 2k+1) = normal pair k. */
 void gpro_get_mover_state(const gpro_env_cfg *cfg, int64_t num_envs, uint64_t seed, uint64_t tick, int64_t env_id_offset, int32_t which,
                           int32_t n_sel, const int32_t *mover_idx, double z_report, int32_t add_noise, const double *pos, const double *vel,
                           const double *acc, const double *mover_rot, double *out);

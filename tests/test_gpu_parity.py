@@ -1109,7 +1109,7 @@ def test_state_getters_match_the_reference_getters(gpr, oracle, precision):
             assert np.all(np.abs(sd / sn[which] - 1.0) < 0.03), (tag, nm, sd)
             assert abs(float(d.mean())) < 0.02 * sn[which]
             big.close()
-        if precision == 'f64':  # the engine's noise stream, bit for bit (kind 5 of gpr-rng-v1)
+        if precision == 'f64':  # the engine's noise stream, bit for bit (kind 5 of gpr-rng-v2)
             o = oracle.OraclePlanningEnv(np.ones((4, 4)), M, E, std_noise=sn)
             o.pos[:], o.vel[:], o.acc[:] = env.pos.cpu().numpy(), env.vel.cpu().numpy(), env.acc.cpu().numpy()
             o.seed, o.tick = env.get_rng_state()
