@@ -596,7 +596,7 @@ def main():
                 for nm, B in ((1, 273), (2, 401)):
                     r = timed_pushing(args, local_rank, 4096, nm)
                     shapes[f'config3: pushing env, {nm} mover(s) x 4096 envs, one launch per step'] = {
-                        'what': 'BenchmarkPushingEnv (contact model gpr-push-v2, engine-defined: parity unpinned)' + (' -- the reference has 1 mover' if nm == 1 else ' -- BASELINE config 3'),
+                        'what': 'BenchmarkPushingEnv (contact model gpr-push-v3, engine-defined: parity unpinned)' + (' -- the reference has 1 mover' if nm == 1 else ' -- BASELINE config 3'),
                         'env_steps_per_s': r['env_steps_per_s'], 'step_us': r['step_us'],
                         'roofline': {'bound': 'hbm', 'achieved': B * 4096 / (r['step_us'] * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                      'frac': B * 4096 / (r['step_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'gpr::k_push', 'kernel_us': r['step_us'],

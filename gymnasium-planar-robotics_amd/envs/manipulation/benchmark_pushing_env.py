@@ -10,9 +10,10 @@ and TimeLimit (50) as the registered ``BenchmarkPushingEnv-v0``.
 termination / info rules, the reset sampling rules, the wall check. **Not pinned**: contact. The reference hands mover-object and
 object-tile contact, friction and the soft impedance hold of the mover's orientation to MuJoCo; MuJoCo is not available to this
 build and no reference test exercises contact. The kernels therefore integrate the engine's own planar rigid-body model
-``gpr-push-v2`` (include/gpr.h): 3-DoF boxes, separating-axis contact with at most four points per pair,
-sequential impulses with Coulomb friction and a 20 ms penetration-recovery time constant, Coulomb + torsional friction against the
-tiles, the reference's joint damping and impedance gains on the yaw. It is MuJoCo-like in its parameters, not MuJoCo-equal in its
+``gpr-push-v3`` (include/gpr.h): 3-DoF boxes, separating-axis test, a clipped two-point manifold with a 0.1 mm
+contact margin, the pair's two normal rows solved exactly + one friction row, two block Gauss-Seidel visits per cycle, a 20 ms
+penetration-recovery time constant, Coulomb + torsional friction against the tiles, the reference's joint damping and impedance gains on
+the yaw. It is MuJoCo-like in its parameters, not MuJoCo-equal in its
 trajectories.
 
 **Two movers** (``num_movers=2``; the reference hard-codes one, PU:196): both movers are actuated (action ``(num_envs, 4)``) and

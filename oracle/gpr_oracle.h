@@ -149,8 +149,9 @@ int32_t gpro_planning_step_mt(const gpro_env_cfg *cfg, int64_t num_envs, uint64_
  * observation / reward / terminated / info (PU:457-607), reset sampling predicates (PU:373-417), wall check.
  * UNPINNED -- "parity unpinned": everything that MuJoCo's contact solver does in the reference (mover-object and object-tile
  * contact, friction, the soft impedance hold of the mover's yaw). MuJoCo is not available to this pipeline and no reference
- * test exercises contact, so the contact physics below is the ENGINE'S OWN planar rigid-body model "gpr-push-v2"
- * (documented in DESIGN.md): 3-DoF bodies, OBB-OBB contact by SAT, sequential impulses with Coulomb friction and a
+ * test exercises contact, so the contact physics below is the ENGINE'S OWN planar rigid-body model "gpr-push-v3"
+ * (documented in DESIGN.md section 7 and at push_cycle in gpr_oracle.c): 3-DoF bodies, OBB-OBB contact by SAT, a clipped two-point
+ * manifold with a 0.1 mm margin, the normal block solved exactly (2 x 2 LCP) + one friction row, two block Gauss-Seidel visits, a
  * 20 ms penetration-recovery time constant (MuJoCo's default solref), Coulomb + torsional friction against the tiles,
  * the reference's joint damping (PU:335) and impedance gains (PU:261-267, IMP:42-47) applied to the yaw.
  * ====================================================================================================================== */

@@ -295,7 +295,7 @@ class PushParams(C.Structure):
 
 class OraclePushingEnv:
     """Batched BenchmarkPushingEnv on the CPU oracle (mover control / obs / reward pinned by the reference; contact physics is the
-    engine's own planar model gpr-push-v2 -- parity unpinned, see oracle/gpr_oracle.h). num_movers = 1 is the reference's env,
+    engine's own planar model gpr-push-v3 -- parity unpinned, see oracle/gpr_oracle.h). num_movers = 1 is the reference's env,
     2 the engine-defined variant of BASELINE.json's config 3."""
 
     def __init__(self, num_envs, mover_mass=1.24, mover_half=(0.0775, 0.0775), std_noise=1e-5, num_cycles=40, collision_params=None,

@@ -1,6 +1,6 @@
 """GPU tests of VecBenchmarkPushingEnv.
 
-What the reference pins is tested against fixtures / the reference's rules; the contact physics (engine model gpr-push-v2,
+What the reference pins is tested against fixtures / the reference's rules; the contact physics (engine model gpr-push-v3,
 parity unpinned -- MuJoCo is not available) is tested for HIP == oracle, for invariants any rigid-body contact model must keep
 (momentum under frictionless contact, no energy gain) and for physical sanity."""
 import numpy as np
@@ -78,7 +78,7 @@ def test_step_reset_vs_oracle(gpr, oracle, precision, kw, monkeypatch):
     assert np.abs(_g(genv.pos) - oenv.pos).max() < tol and np.abs(_g(genv.object) - oenv.object).max() < tol
     rng = np.random.default_rng(1)
     lim = genv.j_max if genv.learn_jerk else genv.a_max
-    n_contact = n_term = mism = 0
+    n_contact = n_term = mism = n_events = 0
     worst = 0.0
     for step in range(70):
         # steer towards the object most of the time so that pushing actually happens
@@ -118,6 +118,7 @@ def test_step_reset_vs_oracle(gpr, oracle, precision, kw, monkeypatch):
             assert event.mean() < 0.01 and oerr[:, 3:5].max() < 0.05 and oerr[:, :2].max() < 2e-3, (step, event.mean(), oerr.max(axis=0))
             assert np.abs(_g(obs['observation'])[ok] - o['observation'][ok]).max() < 5e-3, step
             worst = max(worst, float(oerr[:, 3:5].max()))
+            n_events += int(event[agree & safe].sum())
             ok = ok & ~event
         assert np.abs(_g(obs['observation'])[ok] - o['observation'][ok]).max() < tol, step
         assert np.abs(_g(obs['achieved_goal'])[ok] - o['achieved_goal'][ok]).max() < (tol if precision == 'f64' else 5 * tol), step
@@ -127,8 +128,11 @@ def test_step_reset_vs_oracle(gpr, oracle, precision, kw, monkeypatch):
         n_contact += int((np.abs(oenv.object[:, 3:5]).max(axis=1) > 0).sum()); n_term += int(o['terminated'].sum())
     assert n_contact > 100 and n_term > 0, (n_contact, n_term)
     assert mism <= (0 if precision == 'f64' else 5)
+    # gpr-push-v3 (round 4): scratch/push_err.py over 137 000 env-steps of this workload -- observations off by > 1e-4 in 0 % (one mover) /
+    # 0.003 % (two movers) of the env-steps, object velocities off by > 1e-4 m/s in 0.01 % (v2: 0.005-0.008 % / 0.04 % beyond 50x that)
+    assert n_events <= max(3, 5e-4 * 70 * E), (n_events, 70 * E)
     record_metric(f'pushing_step_reset_vs_oracle[{precision}-NM{NM}-E{E}-{"jerk" if kw.get("learn_jerk") else "acc"}-{autoreset}{"-one-lane" if pair == "0" else ""}]',
-                  flag_mismatches=mism, env_steps=70 * E, worst_object_velocity_event=worst, tol=tol)
+                  flag_mismatches=mism, env_steps=70 * E, worst_object_velocity_event=worst, events=n_events, tol=tol)
     genv.close()
 
 
