@@ -1165,3 +1165,51 @@ def test_exhausted_reset_searches_and_clipped_actions_are_counted(gpr, oracle):
     ok.step(a)
     assert ok.diagnostics()['actions_clipped'] == 600
     env.close(); ok.close()
+
+
+@pytest.mark.parametrize('M,n,precision', [(4, 3, 'f64'), (12, 7, 'f64'), (16, 10, 'f32'), (8, 5, 'f64')])
+def test_exhausted_searches_of_auto_resets_are_counted_exactly(gpr, M, n, precision):
+    """GPR_CNT_RESET_EXHAUSTED through the step kernels' own reset paths (the block's queue for up to 8 lanes per env, the shared searches of
+    the 16-lane kernels, gpr_step_n's in-wavefront resets): a search that finds a valid set within max_reset_trials returns a VALID set, an
+    exhausted one keeps its last, INVALID candidate -- so the counter must equal the number of invalid start sets + invalid goal sets among
+    the envs that were reset, which the stand-alone operators can count from the outside."""
+    E, trials = 1024, 6
+    env = gpr.VecBenchmarkPlanningEnv(np.ones((n, n)), M, num_envs=E, precision=precision, max_reset_trials=trials, std_noise=0.0, warn_on_reset=False)
+    env.reset(seed=7)
+
+    def invalid_sets(xy):  # [K, M, 2] float64 -> (wall | pair with the safety offsets, PL:379-383), (wall | closer than min_goal_dist, PL:403-413)
+        K = xy.shape[0]
+        q = np.zeros((K * M, 7)); q[:, :2] = xy.reshape(-1, 2); q[:, 3] = 1.0
+        wall = ~env.qpos_is_valid(q, 0.11, add_safety_offset=True).bool().cpu().numpy().reshape(K, M).all(axis=1)
+        pair = env.check_mover_collision(q.reshape(K, M, 7), 0.11, add_safety_offset=True).cpu().numpy()
+        d = np.linalg.norm(xy[:, :, None, :] - xy[:, None, :, :], axis=-1) + np.eye(M)[None] * 10.0
+        return wall | pair, wall | (d.min(axis=(1, 2)) < env.min_goal_dist)
+
+    base = env.diagnostics()['reset_exhausted']
+    s_bad, g_bad = invalid_sets(env.pos.double().cpu().numpy().reshape(E, M, 2)), invalid_sets(env.goals.double().cpu().numpy().reshape(E, M, 2))
+    want = int(s_bad[0].sum() + g_bad[1].sum())
+    slack = 0 if precision == 'f64' else 3   # (float builds compare squared distances in float: a set within an ulp of a limit may be judged differently here)
+    assert abs(base - want) <= slack and (want > 0 or M == 4), (base, want)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    total = base
+    n_reset = 0
+    for t in range(12):
+        a = (torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10).to(env.dtype)
+        obs, rew, term, trunc, info = env.step(a)
+        done = (term | trunc).cpu().numpy()
+        n_reset += int(done.sum())
+        s_bad = invalid_sets(env.pos.double().cpu().numpy().reshape(E, M, 2)[done])[0] if done.any() else np.zeros(0, bool)
+        g_bad = invalid_sets(env.goals.double().cpu().numpy().reshape(E, M, 2)[done])[1] if done.any() else np.zeros(0, bool)
+        total += int(s_bad.sum() + g_bad.sum())
+        assert abs(env.diagnostics()['reset_exhausted'] - total) <= slack * (t + 2), (t, env.diagnostics(), total)
+    assert n_reset > E // 4
+    # the same through gpr_step_n (resets inside the wavefront that stepped the env)
+    T = 6
+    acts = (torch.rand(T, E, 2 * M, device='cuda', generator=g) * 20 - 10).to(env.dtype)
+    roll = env.alloc_rollout(T)
+    before = env.diagnostics()['reset_exhausted']
+    env.step_n(acts, roll)
+    after = env.diagnostics()['reset_exhausted']
+    n_done = int(((roll['terminated'] | roll['truncated']) != 0).sum())
+    assert n_done > 0 and after >= before and (M == 4 or after > before)
+    env.close()
