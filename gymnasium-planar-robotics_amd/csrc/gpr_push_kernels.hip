@@ -86,7 +86,7 @@ template <typename RT> __device__ __forceinline__ void p3_forces_object(const Pu
 }
 
 // 2. contact geometry of the pair (mover m, object o); dx, dy = object centre - mover centre (world). Returns whether some env of the
-// wavefront has a contact point (wave-uniform); q.np == 0 for the lanes without one (their rows hold finite junk that nothing uses).
+// wavefront is within reach (wave-uniform); q.np == 0 for the lanes without a contact point (their rows hold finite junk that nothing uses).
 template <typename RT>
 __device__ __forceinline__ bool p3_geometry(const PushCst<RT> &Q, RT dt, const Body<RT> &m, const Body<RT> &o, RT dx, RT dy, P3Pair<RT> &q) {
     q.np = 0; q.nx = (RT)0; q.ny = (RT)0; q.l0 = (RT)0; q.l1 = (RT)0; q.jt = (RT)0;
@@ -106,55 +106,67 @@ __device__ __forceinline__ bool p3_geometry(const PushCst<RT> &Q, RT dt, const B
     const RT d2 = fma_(lx, c, ly * s), d3 = fma_(ly, c, -(lx * s));
     const RT ov0 = (Q.ax + ro01) - absr(lx), ov1 = (Q.ay + ro01) - absr(ly);
     const RT ov2 = (fma_(Q.ax, ac, Q.ay * as) + Q.h) - absr(d2), ov3 = (fma_(Q.ax, as, Q.ay * ac) + Q.h) - absr(d3);
+    // (ONE wave-level decision per pair and cycle, the broad phase above: a decision that hangs on a vector compare stalls its wavefront for
+    //  40-60 clocks, and the wavefront that sets the kernel's duration -- an env pushing through all 40 cycles -- never takes the early exits)
     bool touch = in_range & !(min_(min_(ov0, ov1), min_(ov2, ov3)) < (RT)-PUSH3_MARGIN);
-    if (__ballot(touch) == 0ull) return false;
     int k = 0;
     RT best = ov0;
     { const bool t = ov1 < best; best = t ? ov1 : best; k = t ? 1 : k; }
     { const bool t = ov2 < best; best = t ? ov2 : best; k = t ? 2 : k; }
     { const bool t = ov3 < best; best = t ? ov3 : best; k = t ? 3 : k; }
-    // reference box: centre (rcx, rcy), outward normal (rnx, rny) towards the incident box, half extents en (along the normal) and et
-    // (along the face); incident box: centre (icx, icy), axes (ux, uy), (vx, vy), half extents hu, hv. (nlx, nly): mover -> object.
+    // THE MANIFOLD IN A CANONICAL FRAME. The oracle states it for a general reference box (centre, normal, tangent: oracle/gpr_oracle.c
+    // push3_geometry); here the same points are found in the REFERENCE box's own frame, turned so that the reference normal is +x: the
+    // reference box A is axis-aligned with half extents (en, et), the incident box B sits at (pn > 0, pt) under the rotation (cc, ss) with
+    // half extents (bu, bv). Getting there takes selects only -- which box is A, a swap of the coordinates when the axis is a "y" axis, a
+    // mirror image when B lies on the negative side -- and the two reflections flip the sign of every cross product (`odd`); what was a
+    // dot product with a general normal and tangent is now a coordinate (~70 fewer instructions per contact cycle than the general form).
     const bool mref = k < 2, kx = (k == 0) | (k == 2);  // the mover's face is the reference face; the axis is an "x" axis of its box
-    const RT sg = csign_((RT)1, k == 2 ? d2 : d3);
-    const RT nlx = mref ? (kx ? csign_((RT)1, lx) : (RT)0) : sg * (kx ? c : -s);
-    const RT nly = mref ? (kx ? (RT)0 : csign_((RT)1, ly)) : sg * (kx ? s : c);
-    const RT rcx = mref ? (RT)0 : lx, rcy = mref ? (RT)0 : ly;
-    const RT rnx = mref ? nlx : -nlx, rny = mref ? nly : -nly;
-    const RT en = mref ? (kx ? Q.ax : Q.ay) : Q.h, et = mref ? (kx ? Q.ay : Q.ax) : Q.h;
-    const RT icx = mref ? lx : (RT)0, icy = mref ? ly : (RT)0;
-    const RT ux = mref ? c : (RT)1, uy = mref ? s : (RT)0, vx = mref ? -s : (RT)0, vy = mref ? c : (RT)1;
-    const RT hu = mref ? Q.h : Q.ax, hv = mref ? Q.h : Q.ay;
-    // incident face: the one whose outward normal is most opposed to the reference normal
-    const RT pu = fma_(rnx, ux, rny * uy), pv = fma_(rnx, vx, rny * vy);
-    const bool fu = absr(pu) >= absr(pv);
-    const RT sgn = -csign_((RT)1, fu ? pu : pv);
-    const RT fx = fu ? sgn * hu * ux : sgn * hv * vx, fy = fu ? sgn * hu * uy : sgn * hv * vy;  // face centre offset from the incident centre
-    const RT ex = fu ? hv * vx : hu * ux, ey = fu ? hv * vy : hu * uy;                          // half edge vector
-    const RT bx = (icx + fx) - rcx, by = (icy + fy) - rcy;                    // face centre relative to the reference centre
-    const RT pax = bx - ex, pay = by - ey, pbx = bx + ex, pby = by + ey;      // the incident segment's ends
-    const RT tx = -rny, ty = rnx;
-    const RT sa = fma_(pax, tx, pay * ty), sb = fma_(pbx, tx, pby * ty);      // lateral coordinates on the reference face
-    const RT da = en - fma_(pax, rnx, pay * rny), db = en - fma_(pbx, rnx, pby * rny);  // depths below the reference face
-    touch = touch & !((min_(sa, sb) > et) | (max_(sa, sb) < -et));            // the segment passes the face by
+    // A = reference box: the mover (frame: the mover's) or the object (frame: the object's; the mover sits at -(d2, d3) there, turned by -yaw)
+    const RT qx_ = mref ? lx : -d2, qy_ = mref ? ly : -d3;
+    const RT srot = mref ? s : -s;
+    const RT eAx = mref ? Q.ax : Q.h, eAy = mref ? Q.ay : Q.h, eBu = mref ? Q.h : Q.ax, eBv = mref ? Q.h : Q.ay;
+    // a "y" axis: exchange the coordinates (B's axes exchange their roles: rotation (c, -s), extents exchanged)
+    const RT pn_s = kx ? qx_ : qy_, pt = kx ? qy_ : qx_;
+    const RT en = kx ? eAx : eAy, et = kx ? eAy : eAx;
+    const RT bu = kx ? eBu : eBv, bv = kx ? eBv : eBu;
+    // B on the negative side: mirror image (rotation (c, -s) again)
+    const bool neg = pn_s < (RT)0;
+    const RT pn = absr(pn_s);
+    const RT ss = (kx != neg) ? srot : -srot, cc = c;
+    const bool odd = (!kx) != neg;  // parity of the reflections
+    // incident face: the one whose outward normal is most opposed to +x; B's axes: u = (cc, ss), v = (-ss, cc)
+    const bool fu = absr(cc) >= absr(ss);
+    const RT sgn = fu ? -csign_((RT)1, cc) : csign_((RT)1, ss);
+    const RT hf = fu ? sgn * bu : sgn * bv, he = fu ? bv : bu;            // signed half extent along the face normal, half extent along the edge
+    const RT fx = fu ? hf * cc : -(hf * ss), fy = fu ? hf * ss : hf * cc; // face centre offset from B's centre
+    const RT ex = fu ? -(he * ss) : he * cc, ey = fu ? he * cc : he * ss; // half edge vector
+    const RT bx = pn + fx, by = pt + fy;                                  // face centre relative to A's centre
+    const RT pax = bx - ex, sa = by - ey, pbx = bx + ex, sb = by + ey;    // the incident segment's ends: (x, lateral coordinate)
+    const RT da = en - pax, db = en - pbx;                                // depths below the reference face
+    touch = touch & !((min_(sa, sb) > et) | (max_(sa, sb) < -et));        // the segment passes the face by
     const RT inv = Math<RT>::div_((RT)1, sb - sa);
     const RT ta = (min_(max_(sa, -et), et) - sa) * inv, tb = (min_(max_(sb, -et), et) - sa) * inv;  // cut to [-et, et] along the segment
-    const RT qx0 = fma_(ta, pbx - pax, pax) + rcx, qy0 = fma_(ta, pby - pay, pay) + rcy, dp0 = fma_(ta, db - da, da);
-    const RT qx1 = fma_(tb, pbx - pax, pax) + rcx, qy1 = fma_(tb, pby - pay, pay) + rcy, dp1 = fma_(tb, db - da, da);
+    const RT ex2 = pbx - pax, ey2 = sb - sa, dd = db - da;
+    const RT qx0 = fma_(ta, ex2, pax), qy0 = fma_(ta, ey2, sa), dp0 = fma_(ta, dd, da);
+    const RT qx1 = fma_(tb, ex2, pax), qy1 = fma_(tb, ey2, sa), dp1 = fma_(tb, dd, da);
     // points with depth >= -margin, the deeper one first
     const bool sw = dp1 > dp0;
     const RT e0 = sw ? dp1 : dp0, e1 = sw ? dp0 : dp1;
     touch = touch & !(e0 < (RT)-PUSH3_MARGIN);
-    if (__ballot(touch) == 0ull) return false;
     bool two = e1 >= (RT)-PUSH3_MARGIN;
     const RT p0x = sw ? qx1 : qx0, p0y = sw ? qy1 : qy0;
     const RT p1x = two ? (sw ? qx0 : qx1) : p0x, p1y = two ? (sw ? qy0 : qy1) : p0y;
     const RT d0 = e0, d1 = two ? e1 : (RT)0;
-    // rows: r x n and r x t are the same in every frame; the mover's lever arm is the point itself, the object's the point - (lx, ly)
-    const RT mxc = (RT)0.5 * (p0x + p1x), myc = (RT)0.5 * (p0y + p1y);        // friction row: midpoint of the points
-    q.rmn0 = fma_(p0x, nly, -(p0y * nlx)); q.ron0 = fma_(p0x - lx, nly, -((p0y - ly) * nlx));
-    q.rmn1 = fma_(p1x, nly, -(p1y * nlx)); q.ron1 = fma_(p1x - lx, nly, -((p1y - ly) * nlx));
-    q.rmt = fma_(mxc, nlx, myc * nly); q.rot_ = fma_(mxc - lx, nlx, (myc - ly) * nly);
+    // rows. In the canonical frame the reference normal is +x: r x (+x) = -r.y, r . (+x) = r.x, for the lever arms r = point (from A's
+    // centre) and point - (pn, pt) (from B's). The contact normal n points from the mover to the object: +x if the mover is A, -x if it is
+    // B; an odd number of reflections flips the sign of the cross products once more.
+    const RT mxc = (RT)0.5 * (p0x + p1x);                                  // friction row: midpoint of the points (only its x matters)
+    const bool flip = mref != odd;                                         // r x n = -y (mover is A, even) ... = +y
+    const RT y0a = flip ? -p0y : p0y, y1a = flip ? -p1y : p1y;             // cross products of A's lever arms with n
+    const RT y0b = flip ? pt - p0y : p0y - pt, y1b = flip ? pt - p1y : p1y - pt;  // ... of B's
+    q.rmn0 = mref ? y0a : y0b; q.ron0 = mref ? y0b : y0a;
+    q.rmn1 = mref ? y1a : y1b; q.ron1 = mref ? y1b : y1a;
+    q.rmt = mref ? mxc : pn - mxc; q.rot_ = mref ? mxc - pn : -mxc;
     const RT imm = Q.inv_mm + Q.inv_mo;
     const RT wm0 = q.rmn0 * Q.inv_Im, wo0 = q.ron0 * Q.inv_Io, wm1 = q.rmn1 * Q.inv_Im, wo1 = q.ron1 * Q.inv_Io;
     const RT wmt = q.rmt * Q.inv_Im, wot = q.rot_ * Q.inv_Io;
@@ -170,7 +182,10 @@ __device__ __forceinline__ bool p3_geometry(const PushCst<RT> &Q, RT dt, const B
     q.i00 = Math<RT>::div_((RT)1, q.a00); q.i11 = Math<RT>::div_((RT)1, q.a11); q.idet = Math<RT>::div_((RT)1, det); q.itt = Math<RT>::div_((RT)1, q.att);
     q.bias0 = Math<RT>::div_(d0, d0 >= (RT)0 ? Q.tc : dt);  // recovery; speculative: the gap may close within the cycle, not more
     q.bias1 = Math<RT>::div_(d1, d1 >= (RT)0 ? Q.tc : dt);
-    q.nx = fma_(nlx, cm, -(nly * sm)); q.ny = fma_(nlx, sm, nly * cm);
+    // the normal in the world: the reference box's axis, signed towards the object
+    const RT Cw = mref ? cm : co, Sw = mref ? sm : so;
+    const RT sN = (mref != neg) ? (RT)1 : (RT)-1;                           // (+1 for A = mover and B on the positive side; A = object: reversed)
+    q.nx = sN * (kx ? Cw : -Sw); q.ny = sN * (kx ? Sw : Cw);
     q.np = touch ? (two ? 2 : 1) : 0;
     return true;
 }
@@ -453,6 +468,24 @@ __device__ __forceinline__ PushObs<RT, NM> push_reset_one(const KParams &P, cons
     constexpr int NSELF = 8;
     bool pending = need;
     int n_tried = 0;
+    // NO position at all keeps the distance when even the farthest corner of the object's range is within min_mo_dist of a mover (0.75 %
+    // of the mover starts on the default layout: the reference loops for ever there): every one of the max_trials candidates then fails
+    // and the last one stands -- taken directly (and counted, GPR_CNT_RESET_EXHAUSTED) instead of after 10 000 trials, 156 rounds of the
+    // whole wavefront (at 65 536 envs some wavefront paid that in every step: 66 vs 47 us). 1e-6 of slack for the candidates' rounding.
+    if (X.cand == nullptr) {
+        bool none = false;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const RT fx = max_(absr(Q.omin_x - p[i].x), absr(Q.omax_x - p[i].x)), fy = max_(absr(Q.omin_y - p[i].y), absr(Q.omax_y - p[i].y));
+            none |= Math<RT>::sqrt_(fx * fx + fy * fy) <= Q.min_mo_dist * (RT)(1.0 - 1e-6);
+        }
+        none &= pending;
+        if (__ballot(none) != 0ull) {  // (wave-uniform; rare)
+            RT cx, cy;
+            candidate(ks[0], e, max_trials - 1, cx, cy);
+            if (none) { ox = cx; oy = cy; pending = false; n_tried = max_trials; if (lead) diag_add(P, 0, 1u); }
+        }
+    }
     for (int trial = 0; trial < NSELF && trial < max_trials; ++trial) {
         if (__ballot(pending) == 0ull) break;
         RT cx, cy;
