@@ -220,6 +220,45 @@ class VecBenchmarkPlanningEnvSubBatched:
             self.enable_episode_counters()
         return distributed.all_reduce_sum(self.read_episode_counters())
 
+    # the reference's warnings (counted on the device, see VecBasicPlanarRoboticsEnv) and its state getters, over all sub-batches
+    def count_clipped_actions(self, enable: bool = True) -> None:
+        for s in self.subs:
+            s.count_clipped_actions(enable)
+
+    def diagnostics(self) -> dict[str, int]:
+        self.synchronize()
+        ds = [s.diagnostics() for s in self.subs]
+        return {k: sum(d[k] for d in ds) for k in ds[0]}
+
+    def warn_diagnostics(self) -> dict[str, int]:
+        self.synchronize()
+        ds = [s.warn_diagnostics() for s in self.subs]
+        return {k: sum(d[k] for d in ds) for k in ds[0]}
+
+    def _getter(self, name: str, *args, **kw) -> torch.Tensor:
+        self.synchronize()
+        out = torch.cat([getattr(s, name)(*args, **kw) for s in self.subs], dim=0)
+        self.wait_for_caller()  # (the gathers ran on the caller's stream; the next step kernels rewrite what they read)
+        return out
+
+    def get_mover_qpos(self, mover_name: str, add_noise: bool = False) -> torch.Tensor:
+        return self._getter('get_mover_qpos', mover_name, add_noise)
+
+    def get_mover_qvel(self, mover_name: str, add_noise: bool = False) -> torch.Tensor:
+        return self._getter('get_mover_qvel', mover_name, add_noise)
+
+    def get_mover_qacc(self, mover_name: str, add_noise: bool = False) -> torch.Tensor:
+        return self._getter('get_mover_qacc', mover_name, add_noise)
+
+    def get_mover_qpos_arr(self, mover_names: list[str], add_noise: bool = False) -> torch.Tensor:
+        return self._getter('get_mover_qpos_arr', mover_names, add_noise)
+
+    def get_mover_qvel_arr(self, mover_names: list[str], add_noise: bool = False) -> torch.Tensor:
+        return self._getter('get_mover_qvel_arr', mover_names, add_noise)
+
+    def get_mover_qacc_arr(self, mover_names: list[str], add_noise: bool = False) -> torch.Tensor:
+        return self._getter('get_mover_qacc_arr', mover_names, add_noise)
+
     def state_dict(self) -> dict[str, Any]:
         self.synchronize()
         return {'subs': [s.state_dict() for s in self.subs]}

@@ -867,6 +867,12 @@ def test_parallel_env_with_sub_batches_equals_one_launch(gpr):
         n_done += int((ra[2]['mover_0'] | ra[3]['mover_0']).sum())
     assert n_done > E
     assert torch.equal(one.state(), sub.state())
+    # getters and diagnostics of the sub-batched env = those of the one-launch env (noise streams are keyed by global env id; the call counters agree)
+    names = [one.agents[3], one.agents[0], one.agents[15]]
+    for nm in ('qpos', 'qvel', 'qacc'):
+        assert torch.equal(getattr(one.env, f'get_mover_{nm}_arr')(names), getattr(sub.env, f'get_mover_{nm}_arr')(names)), nm
+    assert torch.equal(one.env.get_mover_qpos('mover_5', add_noise=True), sub.env.get_mover_qpos('mover_5', add_noise=True))
+    assert one.env.diagnostics() == sub.env.diagnostics()
     # bound outputs: the views land in caller-owned tensors
     z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device='cuda')  # noqa: E731
     outs = dict(observation=z(E, 2 * M), achieved_goal=z(E, 2 * M), desired_goal=z(E, 2 * M), reward=z(E), terminated=z(E, dtype=torch.uint8),
