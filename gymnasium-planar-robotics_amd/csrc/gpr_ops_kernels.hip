@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(BLOCK) k_mover_state(KParams P, int which, int
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= P.E * n_sel) return;
     const int64_t e = i / n_sel;
-    const int m = sel[i - e * n_sel];
+    const int m = clampi(sel[i - e * n_sel], 0, P.M - 1);  // (an index outside the env's movers must not read outside the state tensors)
     const Cst<RT> &C = cst<RT>(P);
     const ST *src = static_cast<const ST *>(which == 0 ? P.pos : which == 1 ? P.vel : P.acc) + (e * P.M + m) * 2;
     RT v[8] = {(RT)src[0], (RT)src[1], (RT)0, (RT)0, (RT)0, (RT)0, (RT)0, (RT)0};

@@ -123,6 +123,8 @@ class VecBenchmarkPlanningParallelEnv(spaces.ParallelEnvBase):
 
     def state(self) -> torch.Tensor:
         """global state ``[E, 6M]``: velocities, positions, goals (the single-agent observation dict, concatenated)"""
+        if self.num_sub_batches > 1:
+            self.env.synchronize()  # (the caller's stream waits for the sub-batches' kernels: their outputs are read below)
         return torch.cat([torch.cat([sb._obs['observation'], sb._obs['achieved_goal'], sb._obs['desired_goal']], dim=1) for sb in self._subs], dim=0)
 
     def close(self) -> None:

@@ -178,8 +178,8 @@ int gpr_read_diagnostics(gpr_env *env, uint64_t *totals_host /* [2] */, void *hi
 
 /* get_mover_qpos / get_mover_qvel / get_mover_qacc and get_mover_qpos_arr / _qvel_arr / _qacc_arr (BE:801-855, 1244-1290) for every env
  * of the handle. which: 0 qpos -> out [E][n_sel][7] = (x, y, z, qw, qx, qy, qz); 1 qvel -> [E][n_sel][6] = (vx, vy, vz, wa, wb, wc);
- * 2 qacc -> [E][n_sel][6]. mover_idx_dev [n_sel] int32: row j of an env is mover mover_idx[j] (the order of the reference's mover_names
- * argument). z is what the reference reports, the distance between the mover's bottom and the tile's top (BE:821-824: body z minus the
+ * 2 qacc -> [E][n_sel][6]. mover_idx_dev [n_sel] int32 in [0, num_movers): row j of an env is mover mover_idx[j] (the order of the
+ * reference's mover_names argument; an index outside the range is clamped into it). z is what the reference reports, the distance between the mover's bottom and the tile's top (BE:821-824: body z minus the
  * half height) -- constant in this planar engine, passed by the caller (initial_mover_zpos); the quaternion is the identity (planning
  * env) or the yaw rotation (pushing env); z / roll / pitch rates and accelerations are 0. add_noise: Gaussian noise of std_noise[which]
  * on EVERY component, as BE:828 / 841 / 855 add it, from random stream kind 5 of gpr-rng-v2 (key (seed, call counter, 5, global env id,
