@@ -366,6 +366,11 @@ __device__ __forceinline__ PushObs<RT, NM> push_observe(const KParams &P, const 
     return o;
 }
 
+// A noisy read behind a wave-uniform "can it matter at all?" test must stay a BRANCH: left alone the compiler turns the test into selects and
+// every cycle pays the Box-Muller draw (hash, log, sqrt, sin, cos: ~28 instructions, twice per cycle) that one cycle in hundreds needs.
+// An empty volatile asm cannot be executed speculatively, so the block it sits in keeps its branch.
+#define GPR_KEEP_BRANCH() asm volatile("" ::: "memory")
+
 // the value lane L of the wavefront holds (L wave-uniform)
 template <typename RT> __device__ __forceinline__ RT lane_bcast(RT v, int L);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int L) {
@@ -643,7 +648,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                 if constexpr (NOISE) {
                     const RT t0 = mm.vx + C.dt * am.x, t1 = mm.vy + C.dt * am.y, vl = C.v_max - C.band_v;
                     const bool nd = !(t0 * t0 + t1 * t1 < vl * vl) | (vl <= (RT)0);
-                    if (eager | (__ballot(nd & !frozen) != 0ull)) vn = noisy<RT, true>(vn, C.sig_v, keym, 3u * (uint32_t)cyc);
+                    if (eager | (__ballot(nd & !frozen) != 0ull)) { GPR_KEEP_BRANCH(); vn = noisy<RT, true>(vn, C.sig_v, keym, 3u * (uint32_t)cyc); }
                 }
                 R2<RT> vnext;
                 const R2<RT> qaccm = clamp_dyn<RT>(vn, C.v_max, am, C.dt, C.inv_dt, vnext);
@@ -657,6 +662,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                     bool unc;
                     wi = !pos_valid_circle<RT, FULL, true>(T, P, pm.x, pm.y, cw_step, C.band_p, &unc);
                     if (eager | (__ballot(unc & !frozen) != 0ull)) {
+                        GPR_KEEP_BRANCH();
                         const R2<RT> pw = noisy<RT, true>(pm, C.sig_p, keym, 3u * (uint32_t)cyc + 1u);
                         wi = !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
                     }
@@ -668,6 +674,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                 bool hit = pair_hit2<RT>(C, pm, R2<RT>{partner(pm.x), partner(pm.y)}, &d);  // (symmetric in its two points, bit for bit)
                 if constexpr (NOISE) {
                     if (eager | (__ballot((absr(d - pair_thr) <= pair_band) & !frozen) != 0ull)) {
+                        GPR_KEEP_BRANCH();
                         const R2<RT> qm = noisy<RT, true>(pm, C.sig_p, keym, 3u * (uint32_t)cyc + 2u);
                         hit = pair_hit2<RT>(C, qm, R2<RT>{partner(qm.x), partner(qm.y)});
                     }
@@ -695,7 +702,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                         const RT t0 = m[i].vx + C.dt * a[i].x, t1 = m[i].vy + C.dt * a[i].y, vl = C.v_max - C.band_v;
                         nd = !(t0 * t0 + t1 * t1 < vl * vl) | (vl <= (RT)0);
                     }
-                    if (eager | (__ballot(nd & !frozen) != 0ull)) vn = noisy<RT, true>(vn, C.sig_v, key[i], 3u * (uint32_t)cyc);
+                    if (eager | (__ballot(nd & !frozen) != 0ull)) { GPR_KEEP_BRANCH(); vn = noisy<RT, true>(vn, C.sig_v, key[i], 3u * (uint32_t)cyc); }
                 }
                 R2<RT> vnext;
                 if constexpr (JERK) {
@@ -726,6 +733,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                     bool unc;
                     wi = !pos_valid_circle<RT, FULL, true>(T, P, pm.x, pm.y, cw_step, C.band_p, &unc);
                     if (eager | (__ballot(unc & !frozen) != 0ull)) {
+                        GPR_KEEP_BRANCH();
                         const R2<RT> pw = noisy<RT, true>(pm, C.sig_p, key[i], 3u * (uint32_t)cyc + 1u);
                         wi = !pos_valid_circle<RT, FULL>(T, P, pw.x, pw.y, cw_step);
                     }
@@ -740,6 +748,7 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                 hit = pair_hit2<RT>(C, pm0, pm1, &d);
                 if constexpr (NOISE) {
                     if (eager | (__ballot((absr(d - pair_thr) <= pair_band) & !frozen) != 0ull)) {
+                        GPR_KEEP_BRANCH();
                         const R2<RT> q0 = noisy<RT, true>(pm0, C.sig_p, key[0], 3u * (uint32_t)cyc + 2u);
                         const R2<RT> q1 = noisy<RT, true>(pm1, C.sig_p, key[NM - 1], 3u * (uint32_t)cyc + 2u);
                         hit = pair_hit2<RT>(C, q0, q1);
