@@ -644,14 +644,20 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
             R2<RT> accm{pick(acc[0].x, acc[1].x), pick(acc[0].y, acc[1].y)};
             const uint32_t keym = second ? key[1] : key[0];
             for (int cyc = 0; cyc < P.num_cycles; ++cyc) {
+                // PU:419-448. While |v + dt a| stays below v_max - band_v in every lane, no velocity reading can make the clamp fire
+                // (PL:634): the command is the action itself, and neither the reading nor the clamp is evaluated
                 R2<RT> vn{mm.vx, mm.vy};
-                if constexpr (NOISE) {
+                R2<RT> qaccm = am;
+                {
                     const RT t0 = mm.vx + C.dt * am.x, t1 = mm.vy + C.dt * am.y, vl = C.v_max - C.band_v;
                     const bool nd = !(t0 * t0 + t1 * t1 < vl * vl) | (vl <= (RT)0);
-                    if (eager | (__ballot(nd & !frozen) != 0ull)) { GPR_KEEP_BRANCH(); vn = noisy<RT, true>(vn, C.sig_v, keym, 3u * (uint32_t)cyc); }
+                    if (eager | (__ballot(nd & !frozen) != 0ull)) {
+                        GPR_KEEP_BRANCH();
+                        if constexpr (NOISE) vn = noisy<RT, true>(vn, C.sig_v, keym, 3u * (uint32_t)cyc);
+                        R2<RT> vnext;
+                        qaccm = clamp_dyn<RT>(vn, C.v_max, am, C.dt, C.inv_dt, vnext);
+                    }
                 }
-                R2<RT> vnext;
-                const R2<RT> qaccm = clamp_dyn<RT>(vn, C.v_max, am, C.dt, C.inv_dt, vnext);
                 if (!frozen) {  // (both lanes of an env are frozen together: the exchanges inside always find their partner)
                     push_cycle_pair(Q, C.dt, mm, o, qaccm, rel0m, second);
                     accm = qaccm;
@@ -696,13 +702,16 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 R2<RT> vn{m[i].vx, m[i].vy};
+                // (acceleration actions) while |v + dt a| stays below v_max - band_v in every lane, no velocity reading can make the clamp
+                // fire (PL:634): the command is the action itself, and neither the reading nor the clamp is evaluated
+                bool nd = true;
+                if constexpr (!JERK) {
+                    const RT t0 = m[i].vx + C.dt * a[i].x, t1 = m[i].vy + C.dt * a[i].y, vl = C.v_max - C.band_v;
+                    nd = !(t0 * t0 + t1 * t1 < vl * vl) | (vl <= (RT)0);
+                }
+                const bool look = eager | (__ballot(nd & !frozen) != 0ull);
                 if constexpr (NOISE) {
-                    bool nd = true;
-                    if constexpr (!JERK) {
-                        const RT t0 = m[i].vx + C.dt * a[i].x, t1 = m[i].vy + C.dt * a[i].y, vl = C.v_max - C.band_v;
-                        nd = !(t0 * t0 + t1 * t1 < vl * vl) | (vl <= (RT)0);
-                    }
-                    if (eager | (__ballot(nd & !frozen) != 0ull)) { GPR_KEEP_BRANCH(); vn = noisy<RT, true>(vn, C.sig_v, key[i], 3u * (uint32_t)cyc); }
+                    if (look) { GPR_KEEP_BRANCH(); vn = noisy<RT, true>(vn, C.sig_v, key[i], 3u * (uint32_t)cyc); }
                 }
                 R2<RT> vnext;
                 if constexpr (JERK) {
@@ -713,7 +722,8 @@ __global__ void __launch_bounds__(BLOCK) k_push(const KParams P, const PushCst<R
                     const R2<RT> uu{diff ? div_rcp<RT>(acc_p.x - acc[i].x, C.dt, C.inv_dt) : j1.x, diff ? div_rcp<RT>(acc_p.y - acc[i].y, C.dt, C.inv_dt) : j1.y};
                     qacc[i].x = acc[i].x + C.dt * uu.x; qacc[i].y = acc[i].y + C.dt * uu.y;
                 } else {
-                    qacc[i] = clamp_dyn<RT>(vn, C.v_max, a[i], C.dt, C.inv_dt, vnext);
+                    qacc[i] = a[i];
+                    if (look) { GPR_KEEP_BRANCH(); qacc[i] = clamp_dyn<RT>(vn, C.v_max, a[i], C.dt, C.inv_dt, vnext); }
                 }
             }
             // mj_step (BE:1882): engine model gpr-push-v3. An env that has collided stands still (BE:1904-1905): its lanes sit the
