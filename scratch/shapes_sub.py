@@ -2,7 +2,7 @@
 import argparse, sys, numpy as np
 sys.path.insert(0, '.')
 import bench
-args = argparse.Namespace(movers=4, tiles=6, precision='f32', steps=200, warmup=60, min_seconds=0.1)
+args = argparse.Namespace(movers=4, tiles=6, precision='f32', steps=200, warmup=60, min_seconds=0.1, extra_seconds=0.1, regions=1)
 box = {'shape': 'box', 'size': np.array([0.0775, 0.0775])}
 HOLES = np.ones((6, 6)); HOLES[2, 3] = 0; HOLES[4, 1] = 0
 shapes = [('4 movers f32', dict(envs=65536)), ('8 movers', dict(envs=65536, movers=8, tiles=8)), ('16 movers', dict(envs=32768, movers=16, tiles=10)),
