@@ -173,7 +173,9 @@ int gpr_read_counters(gpr_env *env, uint64_t *totals_dev /* [GPR_NUM_COUNTERS], 
 /* opt-in: let the step kernels count the env-steps the reference would print "action is not within the action space" for (BE:1871-1873) */
 int gpr_count_clipped_actions(gpr_env *env, int32_t enable);
 /* The two diagnostics since gpr_create as HOST values: totals_host[0] = GPR_CNT_RESET_EXHAUSTED, [1] = GPR_CNT_ACTIONS_CLIPPED. Waits for
- * hip_stream (a diagnostic read, not a hot-path call); independent of gpr_enable_counters / gpr_read_counters. */
+ * hip_stream (a diagnostic read, not a hot-path call); independent of gpr_enable_counters / gpr_read_counters. Pass the stream the
+ * handle's steps (and gpr_read_counters calls) are issued on: the words are read behind whatever that stream holds, and a step or a
+ * counter reduction running on ANOTHER stream at the same moment may be seen half-way (a count a step too low or too high, never lost). */
 int gpr_read_diagnostics(gpr_env *env, uint64_t *totals_host /* [2] */, void *hip_stream);
 
 /* get_mover_qpos / get_mover_qvel / get_mover_qacc and get_mover_qpos_arr / _qvel_arr / _qacc_arr (BE:801-855, 1244-1290) for every env
