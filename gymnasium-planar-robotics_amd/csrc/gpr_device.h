@@ -265,6 +265,15 @@ template <int LPE, int D> __device__ __forceinline__ double rot(double v) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// the largest value any lane of this lane's env group holds (a cyclic all-reduce: rotations by 1, 2, 4, 8)
+template <int LPE> __device__ __forceinline__ float group_max(float v) {
+    if constexpr (LPE >= 2) v = __builtin_fmaxf(v, rot<LPE, 1>(v));
+    if constexpr (LPE >= 4) v = __builtin_fmaxf(v, rot<LPE, 2>(v));
+    if constexpr (LPE >= 8) v = __builtin_fmaxf(v, rot<LPE, 4>(v));
+    if constexpr (LPE >= 16) v = __builtin_fmaxf(v, rot<LPE, 8>(v));
+    return v;
+}
+
 // (rot(x) - x, rot(y) - y) with the lane permute folded into the subtract: one v_sub_f32_dpp per component instead of
 // v_mov_b32_dpp + v_sub (the compiler pairs the two subtracts into a v_pk_add_f32, which cannot carry a DPP modifier, and
 // then needs the moves). s_nop 1: a DPP read needs two wait states after the VALU write of its source.

@@ -522,6 +522,26 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     constexpr int KC1 = KB - 1, KC2 = 3 * KB - 1, KC3 = 39;  // rungs of the clamp ladder: 1 block, 3 blocks, 40 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
+    // CHORD PRE-TEST OF A BLOCK (circles). Inside a block a mover's velocity changes by at most A dt per cycle -- A = sqrt(2) a_max (the
+    // action is clipped per axis, BE:1871-1873; the speed clamp projects t = v_read + dt a onto the ball of radius v_max, PL:634-643, and
+    // a projection onto a convex set moves a velocity that is inside it no further than the unclamped update would) plus what the noisy
+    // velocity reads of two cycles add -- so the block's positions q_0 .. q_KB have second differences of at most A dt^2 and lie within
+    // chord_dw = A dt^2 KB^2 / 8 (+ float slack) of the chord from q_0 to q_KB. Hence, for every cycle k of the block:
+    //  * wall: the reach is convex and 1-Lipschitz, so reach(q_k) <= max(reach(q_0), reach(q_KB)) + chord_dw;
+    //  * pair: the relative position r = q_i - q_j stays within 2 chord_dw of ITS chord, and on a chord of length L
+    //    |r(t)|^2 = (1 - t) |r_0|^2 + t |r_KB|^2 - t (1 - t) L^2 >= min(|r_0|^2, |r_KB|^2) - L^2 / 4, with L^2 / 4 <= (s_i + s_j) / 2,
+    //    s = the squared displacement of a mover over the block (|a - b|^2 <= 2 |a|^2 + 2 |b|^2).
+    // So ONE reach and ONE pair sweep at the block's end (the start's are the previous block's) decide whether any cycle of the block can
+    // come within the noise band of a wall or of another mover; only if so are the cycles' own reaches formed, from the states the block
+    // kept anyway, and the flagged ones examined as before. The pre-test is conservative, what it lets through is untouched: results stay
+    // bit-identical to evaluating every cycle (GPR_EAGER_NOISE=1; the tests compare). -DGPR_NO_CHORD builds the per-cycle form.
+#ifdef GPR_NO_CHORD
+    constexpr bool CHORD = false;
+#else
+    constexpr bool CHORD = SHAPE == 0;
+#endif
+    const RT chord_a = (RT)1.4143 * C.a_max + (RT)3 * C.band_v * C.inv_dt;
+    const RT chord_dw = chord_a * C.dt * C.dt * (RT)(KB * KB / 8.0) + (RT)2e-6;
     // Box shape on a grid without holes: noise-free the rectangle is axis-aligned (identity quaternion), so its wall test is the
     // circle's with per-axis sizes, "close to a wall" allows for the vertex displacement band_b of a noisy read, and "close to
     // another mover" means centres within the summed circumradii (+ 2 band_b); the exact rectangle tests (BE:559-783,
@@ -570,6 +590,11 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     RT pthr_l = pair_thr;                                  // pair: hit iff d2 <= pthr_l
     RT p0r = every ? INF : pb * pb * (RT)1.00001;          // certainly no hit, whatever the noise, iff d2 > p0r
     const RT pband = every ? INF : pair_band;
+    // chord pre-test: (sqrt(p0r) + 2 chord_dw)^2 <= p0r + chord_padd; a lane that is out (p0r = -1) stays below every value the test forms
+    const RT chord_padd = (RT)4 * chord_dw * (pb * (RT)1.00001 + chord_dw) * (RT)1.0001;
+    // ... which relies on |v| <= v_max + band_v at the block's start (true after every cycle the engine integrated; a caller may have
+    // written anything into the state): a block of the clamp form that starts faster takes the per-cycle path
+    const RT chord_vcap = ((RT)1 + (RT)2 * C.band_v / C.v_max) * ((RT)1 + (RT)2 * C.band_v / C.v_max) * (RT)1.00001;
     // Per-lane integration operands. A frozen env (BE:1904 break, or an env that only resets in this call) keeps its state:
     // its lanes integrate with a zero time step, a zero increment and an unreachable clamp, and compare against wall limits of
     // +inf and pair limits of -1 (never reached).
@@ -635,6 +660,9 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         return true;
     };
 
+    // chord pre-test: the wall reach (block_reach) and the smallest squared pair distance of the CURRENT state -- the start of the next
+    // block's chords; kept up to date by whatever advances the state (a block leaves its end's, exact_cycle its cycle's)
+    RT e_cur = (RT)0, m_cur = INF;
     // ---- one control cycle, everything evaluated in its place: the path of the cycles in which something may happen ----
     auto exact_cycle = [&](int cyc) __attribute__((always_inline)) {
         // _mujoco_step_callback (PL:420-450) + mj_step (BE:1882), see the generic loop for the algebra
@@ -681,15 +709,18 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         if constexpr (FULL) {
             e = wall_reach_centred<RT>(q.x, q.y, cw_thr);
             sp_w = __ballot(!(e < w0));
+            if constexpr (CHORD) e_cur = e;
         } else {
             p.x = p0.x + dp.x; p.y = p0.y + dp.y;
             w_valid = pos_valid_circle<RT, FULL, true>(T, P, p.x, p.y, cw_step, C.band_p, &w_unc);
             sp_w = every ? ~0ull : (__ballot(!w_valid | w_unc) & live_m & ~frozen_m);
+            if constexpr (CHORD) e_cur = __builtin_fmaxf(__builtin_fabsf(q.x - fb_x), __builtin_fabsf(q.y - fb_y) + fb_k);  // (block_reach)
         }
         if constexpr (LPE > 1) {
             if constexpr (SHAPE == 0) {
                 md = pair_min_dist<RT, LPE>(q.x, q.y);
                 sp_p = __ballot(md <= p0r);
+                if constexpr (CHORD) m_cur = md;
             } else {
                 near_b = BoxNear<RT, LPE, 1>::run(q.x, q.y, bnx, bny);
                 sp_p = __ballot(near_b);
@@ -795,6 +826,10 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         if constexpr (SHAPE == 0) return pair_min_dist<RT, LPE>(qx, qy);
         else return BoxNearMetric<RT, LPE, 1>::run(qx, qy, bnx, bny);
     };
+    if constexpr (CHORD) {
+        e_cur = block_reach(q0.x, q0.y);
+        if constexpr (LPE > 1) m_cur = pair_reach(q0.x, q0.y);
+    }
     for (int cyc = 0; cyc < P.num_cycles;) {  // BE:1879
         int n_exact = P.num_cycles - cyc;
         if (fast_ok & (cyc + KB <= P.num_cycles)) {
@@ -812,22 +847,26 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
             }
             if (rows_ok) {
                 R2<RT> dps[KB], dvs[KB];
-                RT es[KB], ms[KB];
+                RT es[KB], ms[KB];  // (the per-cycle form's reaches; the chord form makes them when a block is flagged)
                 RT eacc = -INF, macc = INF;
-                const R2<RT> dp_b = dp, dv_b = dv;  // (box shape: a flagged block is replayed cycle by cycle from here)
+                const R2<RT> dp_b = dp, dv_b = dv;  // (box shape, layouts with holes: a flagged block is replayed cycle by cycle from here)
+                unsigned long long over = 0ull;     // chord form: lanes of a clamp-form block that start it faster than the engine leaves a mover
                 if (needy == 0ull) {
 #pragma unroll
                     for (int j = 0; j < KB; ++j) {
                         integrate(R2<RT>{dv.x + dtl.x, dv.y + dtl.y});
-                        const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
                         dps[j] = dp; dvs[j] = dv;
-                        es[j] = block_reach(q.x, q.y);
-                        eacc = __builtin_fmaxf(eacc, es[j]);
-                        ms[j] = INF;
-                        if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                        if constexpr (!CHORD) {
+                            const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
+                            es[j] = block_reach(q.x, q.y);
+                            eacc = __builtin_fmaxf(eacc, es[j]);
+                            ms[j] = INF;
+                            if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                        }
                     }
                 } else {
                     GPR_WT(wt_clamp += KB;)
+                    if constexpr (CHORD) over = __ballot(speed2(R2<RT>{v0.x + dv.x, v0.y + dv.y}) > vmax2_l * chord_vcap);
                     float2 rd[KB];
                     if constexpr (NOISE) {
 #pragma unroll
@@ -839,16 +878,36 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                         R2<RT> t{v0.x + dvn.x, v0.y + dvn.y}, nv{(RT)0, (RT)0};
                         if constexpr (NOISE) { nv.x = rd[j].x; nv.y = rd[j].y; t.x += nv.x; t.y += nv.y; }
                         integrate(clamp_dv(t, nv, speed2(t), dvn));
-                        const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
                         dps[j] = dp; dvs[j] = dv;
-                        es[j] = block_reach(q.x, q.y);
-                        eacc = __builtin_fmaxf(eacc, es[j]);
-                        ms[j] = INF;
-                        if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                        if constexpr (!CHORD) {
+                            const R2<RT> q{q0.x + dp.x, q0.y + dp.y};
+                            es[j] = block_reach(q.x, q.y);
+                            eacc = __builtin_fmaxf(eacc, es[j]);
+                            ms[j] = INF;
+                            if constexpr (LPE > 1) { ms[j] = pair_reach(q.x, q.y); macc = __builtin_fminf(macc, ms[j]); }
+                        }
                     }
                 }
                 // (the near limit of a lane that is out -- dead, padding, frozen -- is -1: never reached; bnx is its flag for boxes)
-                const bool flagged = (__ballot(!(eacc < w0)) | __ballot(macc <= (SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1)))) != 0ull;
+                bool flagged;
+                if constexpr (CHORD) {
+                    // the chord pre-test (see chord_dw): the block's end against its start
+                    const R2<RT> qe{q0.x + dp.x, q0.y + dp.y};
+                    const RT e_end = block_reach(qe.x, qe.y);
+                    unsigned long long near_p = 0ull;
+                    RT m_end = INF;
+                    if constexpr (LPE > 1) {
+                        m_end = pair_reach(qe.x, qe.y);
+                        const RT ddx = dp.x - dp_b.x, ddy = dp.y - dp_b.y;
+                        const RT s2 = __builtin_fmaf(ddx, ddx, ddy * ddy);
+                        const RT tst = __builtin_fmaf((RT)-0.5, s2 + group_max<LPE>(s2), __builtin_fminf(m_cur, m_end));
+                        near_p = __ballot(tst <= p0r + chord_padd);
+                    }
+                    flagged = (__ballot(!(__builtin_fmaxf(e_cur, e_end) + chord_dw < w0)) | near_p | over) != 0ull;
+                    e_cur = e_end; m_cur = m_end;
+                } else {
+                    flagged = (__ballot(!(eacc < w0)) | __ballot(macc <= (SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1)))) != 0ull;
+                }
                 if ((SHAPE == 1 || !FULL) && flagged) {
                     // box shape: the exact rectangle tests (rotated vertices, table walk, 16 segment pairs per rectangle pair) are
                     // long; instead of one copy of them per cycle of the block, the block is taken back and replayed through
@@ -863,21 +922,30 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                     for (int j = 0; j < KB; ++j) {
                         // (w0 / p0r / wx_l / pthr_l of an env that collided in an earlier cycle of this block are +inf / -1 by now)
                         const RT pnj = SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1);
-                        if ((__ballot(!(es[j] < w0)) | __ballot(ms[j] <= pnj)) == 0ull) continue;
+                        RT ej, mj;
+                        if constexpr (CHORD) {  // the cycle's reaches from the state kept for it
+                            const R2<RT> qj{q0.x + dps[j].x, q0.y + dps[j].y};
+                            ej = block_reach(qj.x, qj.y);
+                            mj = INF;
+                            if constexpr (LPE > 1) mj = pair_reach(qj.x, qj.y);
+                        } else {
+                            ej = es[j]; mj = ms[j];
+                        }
+                        if ((__ballot(!(ej < w0)) | __ballot(mj <= pnj)) == 0ull) continue;
                         GPR_WT(++wt_exact;)
                         const R2<RT> pj{p0.x + dps[j].x, p0.y + dps[j].y};
-                        unsigned long long wraw = __ballot(!(es[j] < wx_l)), hraw = 0ull;
+                        unsigned long long wraw = __ballot(!(ej < wx_l)), hraw = 0ull;
                         {
                         if constexpr (NOISE) {
-                            if (__ballot(!(__builtin_fabsf(wx_l - es[j]) > wband)) != 0ull) {
+                            if (__ballot(!(__builtin_fabsf(wx_l - ej) > wband)) != 0ull) {
                                 const R2<RT> pw = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u));
                                 wraw = __ballot(!(wall_reach_full<RT>(C, pw.x, pw.y, cw_step) < wx_l));
                             }
                         }
                         if constexpr (LPE > 1) {
-                            hraw = __ballot(ms[j] <= pthr_l);  // BE:409, inclusive
+                            hraw = __ballot(mj <= pthr_l);  // BE:409, inclusive
                             if constexpr (NOISE) {
-                                if (__ballot(absr(ms[j] - pthr_l) <= pband) != 0ull) {
+                                if (__ballot(absr(mj - pthr_l) <= pband) != 0ull) {
                                     const R2<RT> pp = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u + R));
                                     hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
                                 }
