@@ -18,7 +18,7 @@ COUNTERS = ('episodes', 'terminated', 'truncated', 'success', 'wall_collision', 
 
 EXPORTS = (
     'gpr_version', 'gpr_last_error', 'gpr_create', 'gpr_destroy', 'gpr_bind_state', 'gpr_seed', 'gpr_get_rng_state', 'gpr_set_rng_state',
-    'gpr_reset', 'gpr_reset_candidates', 'gpr_step', 'gpr_step_many', 'gpr_streams_overlap', 'gpr_step_n', 'gpr_enable_counters', 'gpr_read_counters', 'gpr_count_clipped_actions', 'gpr_read_diagnostics', 'gpr_get_mover_state',
+    'gpr_reset', 'gpr_reset_candidates', 'gpr_step', 'gpr_step_many', 'gpr_streams_overlap', 'gpr_set_wave_budget', 'gpr_step_n', 'gpr_enable_counters', 'gpr_read_counters', 'gpr_count_clipped_actions', 'gpr_read_diagnostics', 'gpr_get_mover_state',
     'gpr_compute_reward', 'gpr_agent_views', 'gpr_push_configure', 'gpr_push_reset', 'gpr_push_reset_opts', 'gpr_push_reset_candidates', 'gpr_push_step', 'gpr_qpos_is_valid', 'gpr_check_mover_collision', 'gpr_check_line_segments_intersect',
     'gpr_get_2D_rect_vertices', 'gpr_check_rectangles_intersect', 'gpr_ensure_max_dyn_val',
 )
@@ -96,6 +96,7 @@ def load() -> C.CDLL:
     lib.gpr_step.argtypes = [vp, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_step_many.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(GprStepOut)), C.POINTER(vp)]
     lib.gpr_streams_overlap.argtypes = [vp, vp, C.POINTER(i32)]
+    lib.gpr_set_wave_budget.argtypes = [vp, i32]
     lib.gpr_step_n.argtypes = [vp, i32, vp, C.POINTER(GprStepOut), vp]
     lib.gpr_compute_reward.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.gpr_agent_views.argtypes = [vp, C.POINTER(GprStepOut), vp, vp, vp]

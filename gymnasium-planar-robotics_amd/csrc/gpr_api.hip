@@ -237,6 +237,18 @@ hipError_t ensure_normal_tables() {
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
+// Thin wavefronts: the most wavefronts a gpr_step launch is spread over by default. One wavefront per SIMD (1 024 on MI355X) for groups of
+// up to 4 lanes per env, two for 8, four for 16 -- measured, us per step as one launch at budgets 0 / 1 024 / 2 048 / 4 096: 4 096 envs x
+// 4 movers 10.9 / 9.3 / 9.6 / 11.2, 8 192 x 4: 11.1 / 10.1 / 10.3 / 12.1, 8 192 x 8: 15.9 / 15.9 / 14.8 / 16.4, 4 096 x 16: 52.9 / 53.0 /
+// 42.6 / 40.0 (the 16-lane kernels share their reset searches over the block's wavefronts: more wavefronts, more searchers).
+int32_t default_wave_budget(int lpe) {
+    if (const char *tw = std::getenv("GPR_THIN_WAVES")) {
+        const long v = std::atol(tw);
+        return (int32_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v));
+    }
+    return 1024 * (lpe >= 16 ? 4 : lpe >= 8 ? 2 : 1);
+}
+
 // The handle's tables, counters and kernel attributes live on ONE device; launching from a thread whose current device is another
 // one would run the kernel there on pointers it cannot reach. Refuse instead of faulting.
 int check_device(gpr_env *e, const char *who) {
@@ -497,11 +509,15 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
     // validation switch: GPR_EAGER_NOISE=1 draws every noise sample of every cycle instead of only those that can matter
     const char *eager = std::getenv("GPR_EAGER_NOISE");
     P.eager_noise = eager && eager[0] == '1';
+    // thin wavefronts (gpr_env_kernels.hip: step_body / launch_kernel): a gpr_step launch whose batch leaves SIMDs idle is spread over up
+    // to this many wavefronts (default_wave_budget; gpr_set_wave_budget changes it, e.g. for handles that step side by side)
+    P.thin_waves = default_wave_budget(e->lpe);
+    P.thin_shift = 0;
     P.wave_timing = nullptr;
 #ifdef GPR_WAVE_TIMING
     // debug build: per-wavefront clocks of the last step kernel, dumped to $GPR_WAVE_TIMING (a file name) by gpr_destroy
     if (std::getenv("GPR_WAVE_TIMING")) {
-        e->wave_timing_words = (size_t)((c.num_envs * e->lpe + 63) / 64) * 16;
+        e->wave_timing_words = (size_t)(std::max<int64_t>((c.num_envs * e->lpe + 63) / 64, (int64_t)P.thin_waves) + BLOCK / 64) * 16;
         if (hipMalloc(&P.wave_timing, e->wave_timing_words * 4) == hipSuccess) (void)hipMemset(P.wave_timing, 0, e->wave_timing_words * 4);
         else P.wave_timing = nullptr;
     }
@@ -572,7 +588,9 @@ int gpr_enable_counters(gpr_env *env, int32_t enable) {
         // one row per wavefront of the step kernels' GRID -- whole blocks: the wavefronts of the last block that hold no env still
         // read and write their (zero) rows. Planning: lpe lanes per env; pushing: up to PUSH_LANES lanes per env (k_push).
         const int64_t lanes = env->push_ready ? std::max<int64_t>(env->lpe, PUSH_LANES) : env->lpe;
-        const size_t rows = (size_t)((env->cfg.num_envs * lanes + BLOCK - 1) / BLOCK) * (size_t)(BLOCK / 64);
+        // (a thin gpr_step launch has up to base.thin_waves wavefronts, rounded up to whole blocks)
+        const size_t rows = std::max((size_t)((env->cfg.num_envs * lanes + BLOCK - 1) / BLOCK) * (size_t)(BLOCK / 64),
+                                     (size_t)((env->base.thin_waves + BLOCK / 64 - 1) / (BLOCK / 64) + 1) * (size_t)(BLOCK / 64));
         if (env->counters && rows > env->counter_rows) {  // (gpr_push_configure came after the table was made: a larger one, counts restart)
             (void)hipDeviceSynchronize();
             (void)hipFree(env->counters);
@@ -588,6 +606,18 @@ int gpr_enable_counters(gpr_env *env, int32_t enable) {
         }
     }
     env->counters_on = enable != 0;
+    return GPR_OK;
+}
+
+int gpr_set_wave_budget(gpr_env *env, int32_t max_wavefronts) {
+    if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_set_wave_budget: NULL handle");
+    const int32_t w = max_wavefronts < 0 ? default_wave_budget(env->lpe) : (max_wavefronts > 65536 ? 65536 : max_wavefronts);
+    if (env->counters && (size_t)w + BLOCK / 64 > env->counter_rows)  // (a launch's grid: the budget rounded up to whole blocks)
+        return fail(env, GPR_E_INVALID, "gpr_set_wave_budget: the counter table was made for fewer wavefronts (set the budget before gpr_enable_counters)");
+#ifdef GPR_WAVE_TIMING
+    if (env->base.wave_timing && (size_t)(w + BLOCK / 64) * 16 > env->wave_timing_words) return fail(env, GPR_E_INVALID, "gpr_set_wave_budget: beyond the timing table");
+#endif
+    env->base.thin_waves = w;
     return GPR_OK;
 }
 

@@ -73,6 +73,9 @@ struct KParams {
     uint32_t *diag;
     int32_t count_clipped;
     unsigned int *wave_timing;  // debug builds (-DGPR_WAVE_TIMING): 8 words per wavefront of the step kernel, else NULL
+    // thin wavefronts (step_body): the most wavefronts a gpr_step launch of this handle may be spread over (host side), and the launch's
+    // log2 of "wavefront lanes / lanes that hold movers" (set by launch_kernel)
+    int32_t thin_waves, thin_shift;
 };
 // BenchmarkPushingEnv additions (include/gpr.h: gpr_push_params), in the compute type
 template <typename RT> struct PushCst {

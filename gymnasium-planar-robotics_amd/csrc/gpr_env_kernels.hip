@@ -353,9 +353,17 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
-    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int mv = (int)(t & (LPE - 1));
-    const int64_t env = t / LPE;
+    // THIN WAVEFRONTS (P.thin_shift, wave-uniform; launch_kernel decides). What a wavefront's step costs beyond its quiet cycles are its
+    // EVENTS -- flagged blocks, cycles on the exact path, clamp-form blocks, resets served -- and their number grows with the envs the
+    // wavefront holds, while a batch that leaves most SIMDs idle pays for the slowest wavefront only. So a small batch is spread over more
+    // wavefronts: only the first 64 >> thin_shift lanes of a wavefront hold movers (the others are dead lanes, as in a batch's last
+    // wavefront), i.e. fewer envs and fewer events per wavefront. Results do not depend on it (random streams are keyed by global env id).
+    const int per = 64 >> P.thin_shift;  // lanes of a wavefront that hold movers (a multiple of LPE)
+    const int lane64 = (int)(threadIdx.x & 63);
+    const int64_t wv = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;  // this wavefront, counted over the grid
+    const int64_t t = wv * per + lane64;
+    const int mv = lane64 & (LPE - 1);
+    const int64_t env = lane64 < per ? t / LPE : P.E;
     const bool live_env = env < P.E;
     const bool live = live_env & (mv < M);
     const int64_t envc = live_env ? env : P.E - 1;  // dead lanes shadow a real env (no OOB, never stored)
@@ -374,7 +382,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // one raw slice of LDS per wavefront: the velocity-reading rows of the cycle loops, then the staging area of the agent views
     __shared__ __align__(16) unsigned char wave_scratch[BLOCK / 64][WAVE_SCRATCH_BYTES];
     unsigned char *const my_scratch = wave_scratch[threadIdx.x >> 6];
-    const int64_t env_block_base = (int64_t)blockIdx.x * (BLOCK / LPE);
+    const int64_t env_block_base = (int64_t)blockIdx.x * (BLOCK / 64) * per / LPE;  // first env of this block
     // RESET QUEUE of the block. A reset is a pure function of (seed, tick, env id): it does not need the env's final state, only
     // the knowledge THAT the env ends in this call -- and that is known early: a TimeLimit truncation (and a next-step-mode
     // reset) before the first cycle, a collision in the cycle it happens. An env is queued the moment it is known to end
@@ -406,7 +414,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         queued = true;
         if constexpr (MULTI) return;
         const int slot = atomicAdd(&reset_count, 1);
-        __hip_atomic_store(&reset_list[slot], (int)(threadIdx.x / LPE) * 2 + (int)reset_only, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (only live lanes queue)
+        __hip_atomic_store(&reset_list[slot], (int)(env - env_block_base) * 2 + (int)reset_only, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (only live lanes queue)
     };
 
     // every HBM read of the step is issued here, before the tables are staged: the latencies overlap
@@ -416,7 +424,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     int el;
     // episode counters (include/gpr.h: GPR_CNT_*): lanes 0..5 of a wavefront own the six words of the wavefront's row
     uint32_t cnt_old = 0u;
-    const int64_t cnt_row = t >> 6;
+    const int64_t cnt_row = wv;
     RT c, c1;
     if (carried) {
         a = carry->a_next; p = carry->p; v = carry->v; g = carry->g; acc = carry->acc; el = carry->el; cnt_old = carry->cnt;
@@ -1262,15 +1270,17 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     unsigned tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     {
-    const int64_t t = (int64_t)blockIdx.x * BLOCK + tid_e;
-    const int mv = (int)(tid_e & (LPE - 1));
-    const int64_t env = t / LPE;
+    const int lane64 = (int)(tid_e & 63);
+    const int64_t wv = ((int64_t)blockIdx.x * BLOCK + tid_e) >> 6;
+    const int64_t t = wv * per + lane64;
+    const int mv = lane64 & (LPE - 1);
+    const int64_t env = lane64 < per ? t / LPE : P.E;
     const bool live_env = env < P.E;
     const bool live = live_env & (mv < M);
     const int64_t envc = live_env ? env : P.E - 1;
     const int mvc = mv < M ? mv : M - 1;
     const int64_t idx = envc * (2 * (int64_t)M) + 2 * mvc;
-    const int64_t cnt_row = t >> 6;
+    const int64_t cnt_row = wv;
     wc_m = group_or<LPE>(wc_m);
     mc_m = group_or<LPE>(mc_m);
     const bool wc_step = lane_of(wc_m), mc_step = lane_of(mc_m);
@@ -1332,7 +1342,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         const int lane = (int)__lane_id(), ei = lane / LPE;
         const int64_t env_w0 = (t - lane) / LPE;  // first env of this wavefront
         int64_t n_env64 = P.E - env_w0;
-        const int n_env = (int)(n_env64 < 0 ? 0 : (n_env64 > 64 / LPE ? 64 / LPE : n_env64));
+        const int n_env = (int)(n_env64 < 0 ? 0 : (n_env64 > per / LPE ? per / LPE : n_env64));
         const unsigned long long need_m = __ballot(need);
         const int env_bytes = M * W * (int)sizeof(ST);
         int epp = WAVE_SCRATCH_BYTES / env_bytes;  // whole envs per pass
@@ -1665,8 +1675,17 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     } else if constexpr (GPR_ENV_PART == 1 && !WIDE) {
         return hipErrorInvalidValue;                                  // (nor this one in the other)
     } else {
+    // thin wavefronts (step_body): a batch that leaves SIMDs idle is spread over up to P.thin_waves wavefronts (gpr_api.hip: the handle's
+    // wavefront budget; 0 = never), each holding 64 >> thin_shift lanes of movers. gpr_step only: a gpr_step_n launch keeps whole wavefronts
+    KParams Q = P;
+    Q.thin_shift = 0;
+    if (!is_reset && P.n_steps <= 1) {
+        const int64_t natural = (P.E * LPE + 63) / 64;
+        while ((64 >> (Q.thin_shift + 1)) >= LPE && (natural << (Q.thin_shift + 1)) <= (int64_t)P.thin_waves) ++Q.thin_shift;
+    }
+    const int64_t live_per_block = (int64_t)(BLOCK / 64) * (64 >> Q.thin_shift);
     const int64_t threads = P.E * LPE;
-    const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    const unsigned grid = (unsigned)((threads + live_per_block - 1) / live_per_block);
     const unsigned lds = (FULL && SHAPE == 0 && !Math<RT>::literal) ? 0u : P.table_bytes;
     // the tile tables of a large layout (64 x 64 cells in f64: 47 KB) plus the kernels' static LDS exceed the 64 KB a launch
     // gets by default: raise the kernel's limit once (gfx950 has 160 KB per CU; gpr_create bounds the table size)
@@ -1684,7 +1703,7 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     } else if (P.n_steps > 1) {
         hipLaunchKernelGGL((k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P.step_params, P.n_steps);
     } else {
-        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P);
+        hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, Q);
     }
     return hipGetLastError();
     }

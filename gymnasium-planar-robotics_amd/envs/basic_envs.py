@@ -301,6 +301,12 @@ class VecBasicPlanarRoboticsEnv(spaces.VectorEnvBase):
             v.copy_(torch.as_tensor(sd[k]).to(device=v.device, dtype=v.dtype))
         self.set_rng_state(sd['rng_seed'], sd['rng_tick'])
 
+    def set_wave_budget(self, max_wavefronts: int = -1) -> None:
+        """Thin wavefronts (``include/gpr.h: gpr_set_wave_budget``): the most wavefronts a ``step()`` launch of this env is spread over -- a
+        small batch is cut into more wavefronts holding fewer envs each, which shortens its slowest wavefront; results do not depend on it.
+        0 turns it off, a negative value restores the default. (No reference counterpart: the batch axis is the engine's.)"""
+        _native.check(self._lib.gpr_set_wave_budget(self._handle, int(max_wavefronts)), self._handle)
+
     def enable_episode_counters(self, enable: bool = True) -> None:
         """Let the step kernels count episode ends on the device (per-wavefront popcounts of the done masks; no host sync)."""
         with torch.cuda.device(self.device):

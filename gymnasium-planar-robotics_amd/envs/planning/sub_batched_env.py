@@ -71,6 +71,13 @@ class VecBenchmarkPlanningEnvSubBatched:
             self._ready = [torch.cuda.Event() for _ in range(K)]  # the caller's stream has produced sub-batch k's action
             self._done = [torch.cuda.Event() for _ in range(K)]   # sub-batch k's step kernel is through
         self._handles = (C.c_void_p * K)(*[s._handle for s in self.subs])
+        # thin wavefronts (include/gpr.h: gpr_set_wave_budget): the K handles step side by side, so each may spread a small sub-batch over
+        # its K-th of the wavefronts one handle alone would use
+        import os
+        if K > 1 and not os.environ.get('GPR_THIN_WAVES'):
+            lpe = 1 << max(0, int(self.num_movers) - 1).bit_length()
+            for s in self.subs:
+                _native.check(self._lib.gpr_set_wave_budget(s._handle, 1024 * (4 if lpe >= 16 else 2 if lpe >= 8 else 1) // K), s._handle)
         self._stream_ptrs = (C.c_void_p * K)(*[st.cuda_stream for st in self.streams])
         self._own_outs = (C.POINTER(_native.GprStepOut) * K)(*[C.pointer(s._out) for s in self.subs])
 

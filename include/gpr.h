@@ -143,6 +143,16 @@ int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_de
  * three pairs of 150-us single-wavefront kernels and writes 1 (they overlapped) or 0; both streams are synchronised. */
 int gpr_streams_overlap(void *hip_stream_a, void *hip_stream_b, int32_t *overlap_out);
 
+/* Thin wavefronts: a gpr_step launch whose batch would leave SIMDs idle is spread over more wavefronts, each holding fewer envs (what a
+ * wavefront's step costs beyond its 40 quiet cycles -- flagged blocks, clamp-form blocks, resets served -- grows with the envs it holds,
+ * and a small batch lasts as long as its slowest wavefront). Results do not depend on it: every random stream is keyed by global env id.
+ * max_wavefronts = the most wavefronts one launch of this handle may be spread over; 0 turns it off; negative restores the default
+ * (1 024 x {1, 1, 1, 2, 4} for groups of {1, 2, 4, 8, 16} lanes per env on MI355X's 1 024 SIMDs; GPR_THIN_WAVES overrides it at
+ * gpr_create). Handles that step side by side (gpr_step_many) share the machine: give each its part. Call between launches; with
+ * counters enabled call it before gpr_enable_counters (the per-wavefront counter table is sized by it).
+ * Reference counterpart: none (the batch axis itself is the engine's; BE:1835-1950 steps one env). */
+int gpr_set_wave_budget(gpr_env *env, int32_t max_wavefronts);
+
 /* n_steps env-steps in ONE launch, for open-loop rollouts (random / scripted / replayed actions; the benchmark's rollouts): what
  * n_steps calls of gpr_step do, bit for bit (step i draws from call counter tick + i), without a launch, a grid-wide drain and a
  * whole-batch load burst between two steps. action_dev is [n_steps][E][2M] real; EVERY tensor of `out` (final_* included, if set)

@@ -683,6 +683,68 @@ def test_episode_counters_match_the_flags(gpr, M, n, E):
     env.close()
 
 
+@pytest.mark.parametrize('M,n,E,kw', [(4, 6, 1000, {}), (3, 5, 777, {'precision': 'f64'}), (8, 8, 900, {}), (16, 10, 300, {}), (1, 3, 2000, {}),
+                                      (4, 6, 640, {'collision_params': {'shape': 'box', 'size': np.array([0.0775, 0.0775])}}), (2, 4, 1500, {'autoreset_mode': 'next_step'})])
+def test_thin_wavefronts_equal_whole_wavefronts(gpr, M, n, E, kw):
+    """gpr_set_wave_budget: a small batch spread over more wavefronts (fewer envs in each; down to one env per wavefront here) returns bit
+    for bit what whole wavefronts return -- observations, rewards, flags, state, every auto-reset, and the episode counters' totals"""
+    lay = np.ones((n, n))
+    envs = []
+    for budget in (0, 512, 65536):
+        e = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=E, **kw)
+        e.set_wave_budget(budget)
+        e.enable_episode_counters()
+        e.reset(seed=21)
+        envs.append(e)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    n_done = 0
+    for t in range(50):
+        a = (torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10).to(envs[0].dtype)
+        res = [e.step(a) for e in envs]
+        for r in res[1:]:
+            for k in res[0][0]:
+                assert torch.equal(res[0][0][k], r[0][k]), (t, k)
+            assert torch.equal(res[0][1], r[1]) and torch.equal(res[0][2], r[2]) and torch.equal(res[0][3], r[3]), t
+            for k in ('is_success', 'mover_collision', 'wall_collision'):
+                assert torch.equal(res[0][4][k], r[4][k]), (t, k)
+        n_done += int((res[0][2] | res[0][3]).sum())
+    assert n_done > E // 2
+    tot = [e.read_episode_counters().cpu().numpy() for e in envs]
+    for e in envs[1:]:
+        assert torch.equal(envs[0].pos, e.pos) and torch.equal(envs[0].vel, e.vel) and torch.equal(envs[0].goals, e.goals)
+        assert torch.equal(envs[0].elapsed_steps, e.elapsed_steps)
+    assert np.array_equal(tot[0], tot[1]) and np.array_equal(tot[0], tot[2]) and tot[0][0] == n_done
+    # the budget is refused once the counter table is too small for it, and a NULL handle is an error
+    small = gpr.VecBenchmarkPlanningEnv(lay, M, num_envs=64)
+    small.set_wave_budget(0)
+    small.enable_episode_counters()
+    with pytest.raises(Exception):
+        small.set_wave_budget(65536)
+    small.close()
+    for e in envs:
+        e.close()
+
+
+def test_thin_wavefronts_with_agent_views(gpr):
+    """the per-agent views of the step kernel's epilogue (rows staged per wavefront) under thin wavefronts: the PettingZoo-parallel env at a
+    small batch (spread by default) against the same env with whole wavefronts"""
+    E, M = 500, 6
+    lay = np.ones((7, 7))
+    a_env = gpr.VecBenchmarkPlanningParallelEnv(lay, M, num_envs=E)
+    b_env = gpr.VecBenchmarkPlanningParallelEnv(lay, M, num_envs=E)
+    b_env.env.set_wave_budget(0)
+    a_env.reset(seed=8); b_env.reset(seed=8)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for t in range(30):
+        act = torch.rand(E, 2 * M, device='cuda', generator=g) * 20 - 10
+        acts = {ag: act[:, 2 * i:2 * i + 2] for i, ag in enumerate(a_env.agents)}
+        ra, rb = a_env.step(acts), b_env.step(acts)
+        for part_a, part_b in zip(ra[:4], rb[:4]):
+            for ag in a_env.agents:
+                assert torch.equal(torch.as_tensor(part_a[ag]), torch.as_tensor(part_b[ag])), (t, ag)
+    a_env.close(); b_env.close()
+
+
 def test_large_layout_tables_fit(gpr, oracle):
     """a 64 x 64 layout with holes (GPR_MAX_TILES): the f64 tile tables (~47 KB) plus the kernels' static LDS stay launchable, and the
     verdicts still match the oracle (table bytes vs the 64 KB default LDS limit)"""
@@ -719,7 +781,8 @@ def test_bench_two_ranks_on_one_gpu(gpr):
     assert c['strong_scaling']['envs_total'] == 4096 and c['strong_scaling']['envs_per_gpu'] == 2048
     assert c['strong_scaling']['rollout_launch']['env_steps_per_s'] > 0
     assert 0 < c['done_fraction_per_step'] < 0.5
-    assert c['timed_seconds'] >= 0.06 and c['timed_steps'] % 30 == 0 and c['timed_regions'] == 3 and len(c['headline_spread']['region_seconds']) == 3
+    # (3 regions with the repeat count that first reached 0.02 s: the later ones may fall a few per cent short of it)
+    assert c['timed_seconds'] >= 0.05 and c['timed_steps'] % 30 == 0 and c['timed_regions'] == 3 and len(c['headline_spread']['region_seconds']) == 3
     assert line['strong_value'] == c['strong_scaling']['env_steps_per_s'] > 0
     # north_star's collective is in the DEFAULT line: one all-gather of the [50, E/N, .] rollout buffers per flush, timed
     g = c['rollout_gather']
