@@ -96,6 +96,21 @@ struct PushPtrs {
     int32_t n_cand;
     int32_t lane_shift;                 // log2(lanes per env) of this launch (see k_push: small batches spread over more wavefronts)
 };
+// A kernel reads its KParams (760 bytes = 12 lines of the scalar cache) piecemeal: the compiler loads a field where it is first needed and
+// waits for it there -- nine dependent round trips before the first cycle of the step kernel, each one a miss (every launch has a fresh
+// kernel-argument segment). warm_kernarg() asks for one word of every line at once and waits once: the loads that follow hit the scalar
+// cache. (The words land in registers the compiler knows nothing about after the block, hence the wait inside it.)
+__device__ __forceinline__ void warm_kernarg() {
+    static_assert(sizeof(KParams) <= 12 * 64, "one load per 64-byte line of KParams");
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
+    asm volatile("s_load_dword %0, %12, 0x0\n\ts_load_dword %1, %12, 0x40\n\ts_load_dword %2, %12, 0x80\n\ts_load_dword %3, %12, 0xc0\n\t"
+                 "s_load_dword %4, %12, 0x100\n\ts_load_dword %5, %12, 0x140\n\ts_load_dword %6, %12, 0x180\n\ts_load_dword %7, %12, 0x1c0\n\t"
+                 "s_load_dword %8, %12, 0x200\n\ts_load_dword %9, %12, 0x240\n\ts_load_dword %10, %12, 0x280\n\ts_load_dword %11, %12, 0x2c0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3), "=&s"(w4), "=&s"(w5), "=&s"(w6), "=&s"(w7), "=&s"(w8), "=&s"(w9), "=&s"(w10), "=&s"(w11)
+                 : "s"(kp) : "memory");
+}
 template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
 template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }
 template <> __host__ __device__ __forceinline__ const Cst<double> &cst<double>(const KParams &P) { return P.cd; }

@@ -6,6 +6,7 @@
 //
 // step():  BE:1835-1950 (template), PL:420-450 (control), PL:536-602 (obs/info), PL:459-534 (reward/terminated)
 // reset(): BE:1770-1833, PL:355-418
+#include <type_traits>
 #include "gpr_device.h"
 #include "gpr_host.h"
 
@@ -898,11 +899,12 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                 }
                 // (the near limit of a lane that is out -- dead, padding, frozen -- is -1: never reached; bnx is its flag for boxes)
                 bool flagged;
+                unsigned long long near_w = ~0ull, near_p = ~0ull;  // chord form: lanes whose wall / pair pre-test failed (else: not known apart)
                 if constexpr (CHORD) {
+                    near_p = 0ull;
                     // the chord pre-test (see chord_dw): the block's end against its start
                     const R2<RT> qe{q0.x + dp.x, q0.y + dp.y};
                     const RT e_end = block_reach(qe.x, qe.y);
-                    unsigned long long near_p = 0ull;
                     RT m_end = INF;
                     if constexpr (LPE > 1) {
                         m_end = pair_reach(qe.x, qe.y);
@@ -911,7 +913,9 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                         const RT tst = __builtin_fmaf((RT)-0.5, s2 + group_max<LPE>(s2), __builtin_fminf(m_cur, m_end));
                         near_p = __ballot(tst <= p0r + chord_padd);
                     }
-                    flagged = (__ballot(!(__builtin_fmaxf(e_cur, e_end) + chord_dw < w0)) | near_p | over) != 0ull;
+                    near_w = __ballot(!(__builtin_fmaxf(e_cur, e_end) + chord_dw < w0));
+                    if (over != 0ull) { near_w = ~0ull; near_p = ~0ull; }  // (no bound on such a block: everything is looked at)
+                    flagged = (near_w | near_p) != 0ull;
                     e_cur = e_end; m_cur = m_end;
                 } else {
                     flagged = (__ballot(!(eacc < w0)) | __ballot(macc <= (SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1)))) != 0ull;
@@ -926,31 +930,41 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                 } else {
                 if (flagged) {
                     GPR_WT(++wt_near;)
+                    // The cycles of a flagged block, in order. HW / HP: can a wall / a pair be near at all in this block? The chord
+                    // pre-test proves the other kind clear for EVERY cycle and lane (its reach stays below w0, its distances above p0r:
+                    // no hit, nothing within the noise band), so that kind's metric is not even formed -- the usual flagged block has
+                    // one collision of one kind in it. Same verdicts as looking at both (the per-cycle build, GPR_NO_CHORD, does).
+                    auto examine = [&](auto hw_tag, auto hp_tag) __attribute__((always_inline)) {
+                    constexpr bool HW = decltype(hw_tag)::value, HP = decltype(hp_tag)::value && LPE > 1;
 #pragma unroll
                     for (int j = 0; j < KB; ++j) {
                         // (w0 / p0r / wx_l / pthr_l of an env that collided in an earlier cycle of this block are +inf / -1 by now)
                         const RT pnj = SHAPE == 0 ? p0r : ((RT)0 < bnx ? (RT)0 : (RT)-1);
-                        RT ej, mj;
+                        RT ej = -INF, mj = INF;
                         if constexpr (CHORD) {  // the cycle's reaches from the state kept for it
                             const R2<RT> qj{q0.x + dps[j].x, q0.y + dps[j].y};
-                            ej = block_reach(qj.x, qj.y);
-                            mj = INF;
-                            if constexpr (LPE > 1) mj = pair_reach(qj.x, qj.y);
+                            if constexpr (HW) ej = block_reach(qj.x, qj.y);
+                            if constexpr (HP) mj = pair_reach(qj.x, qj.y);
                         } else {
                             ej = es[j]; mj = ms[j];
                         }
-                        if ((__ballot(!(ej < w0)) | __ballot(mj <= pnj)) == 0ull) continue;
+                        unsigned long long fl = 0ull;
+                        if constexpr (HW) fl |= __ballot(!(ej < w0));
+                        if constexpr (HP) fl |= __ballot(mj <= pnj);
+                        if (fl == 0ull) continue;
                         GPR_WT(++wt_exact;)
                         const R2<RT> pj{p0.x + dps[j].x, p0.y + dps[j].y};
-                        unsigned long long wraw = __ballot(!(ej < wx_l)), hraw = 0ull;
-                        {
-                        if constexpr (NOISE) {
-                            if (__ballot(!(__builtin_fabsf(wx_l - ej) > wband)) != 0ull) {
-                                const R2<RT> pw = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u));
-                                wraw = __ballot(!(wall_reach_full<RT>(C, pw.x, pw.y, cw_step) < wx_l));
+                        unsigned long long wraw = 0ull, hraw = 0ull;
+                        if constexpr (HW) {
+                            wraw = __ballot(!(ej < wx_l));
+                            if constexpr (NOISE) {
+                                if (__ballot(!(__builtin_fabsf(wx_l - ej) > wband)) != 0ull) {
+                                    const R2<RT> pw = noisy<RT, true>(pj, C.sig_p, key, draw_index(cyc + j, 1u));
+                                    wraw = __ballot(!(wall_reach_full<RT>(C, pw.x, pw.y, cw_step) < wx_l));
+                                }
                             }
                         }
-                        if constexpr (LPE > 1) {
+                        if constexpr (HP) {
                             hraw = __ballot(mj <= pthr_l);  // BE:409, inclusive
                             if constexpr (NOISE) {
                                 if (__ballot(absr(mj - pthr_l) <= pband) != 0ull) {
@@ -958,7 +972,6 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                                     hraw = __ballot(pair_min_dist<RT, LPE>(pp.x, pp.y) <= pthr_l);
                                 }
                             }
-                        }
                         }
                         if ((wraw | hraw) != 0ull) {  // BE:1904-1905: the env stops in this cycle
                             wc_m |= wraw;
@@ -971,6 +984,15 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                                 if ((P.autoreset == 1) & live & (mv == 0) & !queued) enqueue(false);
                             }
                         }
+                    }
+                    };
+                    // (groups of up to 4 lanes: 4 movers x 65 536 envs -1.5 %; wider groups lose -- 8 movers +8 %, 16 movers +3 % -- three copies of their long sweeps)
+                    if constexpr (CHORD && LPE > 1 && LPE <= 4) {
+                        if (near_p == 0ull) examine(std::true_type{}, std::false_type{});
+                        else if (near_w == 0ull) examine(std::false_type{}, std::true_type{});
+                        else examine(std::true_type{}, std::true_type{});
+                    } else {
+                        examine(std::true_type{}, std::true_type{});
                     }
                     v.x = v0.x + dv.x; v.y = v0.y + dv.y;
                 }
@@ -1549,6 +1571,9 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                 const int c0 = __hip_atomic_load(&reset_claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int cnt = __hip_atomic_load(&reset_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 n = cnt - c0 < EPW ? cnt - c0 : EPW;
+#ifdef GPR_SERVE_MIN
+                if ((n > 0) & (n < GPR_SERVE_MIN) & !all_through) n = 0;  // (experiment: a claim waits until GPR_SERVE_MIN envs are queued or every wavefront is through)
+#endif
                 if (n <= 0) {
                     n = 0;
                     if (all_through) break;  // (read before the counters: nothing can be queued after it was seen set)
@@ -1603,6 +1628,9 @@ template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, i
 #endif
 __global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? ((Math<RT>::literal && !JERK) ? GPR_LITERAL_WAVES : 4)
                                          : ((SHAPE == 1 && FULL && !Math<RT>::literal) ? GPR_BOX_WAVES : 1)) k_step(const KParams P) {
+#ifndef GPR_NO_WARM_KERNARG
+    warm_kernarg();
+#endif
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:

@@ -8,12 +8,19 @@ sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-5
 cp = {'shape': 'box', 'size': np.array([0.0775, 0.0775])} if (len(sys.argv) > 2 and sys.argv[2] == 'box') else None
 layout = np.ones(({1:3,2:4,4:6,8:8,16:10}[M],) * 2)
 if os.environ.get('WT_HOLES'): layout[2, 2] = 0; layout[3, 4] = 0
-env = gpr.VecBenchmarkPlanningEnv(layout, M, num_envs=E, std_noise=sigma, collision_params=cp, precision=os.environ.get('PREC', 'f32'))
-env.reset(seed=0)
-env.elapsed_steps.copy_(torch.randint(0, 50, (E,), device='cuda', dtype=torch.int32))
-acts = [(torch.rand(E, 2 * M, device='cuda') * 20 - 10).to(env.dtype) for _ in range(8)]
-for i in range(150): env.step_into(acts[i % 8], env._out)
-torch.cuda.synchronize(); env.close()
+SUB = int(os.environ.get('WT_SUB', 1))
+if SUB > 1:  # bench.py's way: WT_SUB sub-batches on their own streams, one gpr_step_many call per step (the dump is the LAST sub-batch's kernel)
+    import argparse, bench
+    args = argparse.Namespace(movers=M, tiles=layout.shape[0], precision=os.environ.get('PREC', 'f32'), steps=300, warmup=60, min_seconds=0.1, extra_seconds=0.1, regions=1)
+    p = bench.Pass(args, 0, 0, 1, envs=E, sub=SUB, std_noise=sigma, collision_params=cp)
+    p.do_steps(600); torch.cuda.synchronize(); p.close()
+else:
+    env = gpr.VecBenchmarkPlanningEnv(layout, M, num_envs=E, std_noise=sigma, collision_params=cp, precision=os.environ.get('PREC', 'f32'))
+    env.reset(seed=0)
+    env.elapsed_steps.copy_(torch.randint(0, 50, (E,), device='cuda', dtype=torch.int32))
+    acts = [(torch.rand(E, 2 * M, device='cuda') * 20 - 10).to(env.dtype) for _ in range(8)]
+    for i in range(150): env.step_into(acts[i % 8], env._out)
+    torch.cuda.synchronize(); env.close()
 d = np.fromfile('gpurun_out/wave_timing.bin', dtype=np.uint32).reshape(-1, 16)
 f = d.astype(np.float64)
 tot, serve, clamp, near, served, rows, direct, due = (f[:, i] for i in range(8))
