@@ -1227,6 +1227,18 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                 if (lane_of(nf)) { p = pc; v = vc; lane_out(); }
             }
         };
+        // chord pre-test of a quiet block (see chord_dw in the throughput loop): no clamp and no velocity read inside such a block, so its
+        // positions have second differences of exactly dt^2 a, |a| <= sqrt(2) a_max -- ONE reach and ONE pair sweep at the block's end
+        // instead of one per cycle; e_curf / m_curf: those of the current state (the start of the next block's chords)
+#ifdef GPR_NO_CHORD
+        constexpr bool CHORDL = false;
+#else
+        constexpr bool CHORDL = !JERK;
+#endif
+        const float dwf = (float)((RT)1.4143 * C.a_max * C.dt * C.dt * (RT)(KB * KB / 8.0)) + 2e-6f;
+        const float paddf = 4.f * dwf * (pbf * 1.00001f + dwf) * 1.0001f;
+        float e_curf = 0.f, m_curf = INFf;
+        if constexpr (CHORDL) reaches(p, e_curf, m_curf);
         while (cyc + KB <= P.num_cycles) {
             if (JERK | (cyc + KB - 1 >= next_c)) {
                 const RT t0 = v.x + dta_d.x, t1 = v.y + dta_d.y, n2 = t0 * t0 + t1 * t1;
@@ -1237,6 +1249,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                         advance(cyc);
                         float e, m;
                         reaches(p, e, m);
+                        e_curf = e; m_curf = m;
                         if ((__ballot(!(e < w0f)) | __ballot(m <= p0f)) != 0ull) literal_cycle(cyc, p, v);
                     }
                     continue;
@@ -1247,18 +1260,41 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
             const R2<RT> vb = v, pb = p;
             float eacc = -INFf, macc = INFf;
             const bool moving = !lane_of(frozen_m);
+            bool flagged;
+            if constexpr (CHORDL) {
 #pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                if (moving) {
-                    v.x = v.x + dta_d.x; v.y = v.y + dta_d.y;
-                    p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
+                for (int j = 0; j < KB; ++j) {
+                    if (moving) {
+                        v.x = v.x + dta_d.x; v.y = v.y + dta_d.y;
+                        p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
+                    }
                 }
-                float e, m;
-                reaches(p, e, m);
-                eacc = __builtin_fmaxf(eacc, e); macc = __builtin_fminf(macc, m);
+                float e_end, m_end;
+                reaches(p, e_end, m_end);
+                unsigned long long near_p = 0ull;
+                if constexpr (LPE > 1) {
+                    const float ddx = (float)(p.x - pb.x), ddy = (float)(p.y - pb.y);
+                    const float s2 = __builtin_fmaf(ddx, ddx, ddy * ddy);
+                    const float tst = __builtin_fmaf(-0.5f, s2 + group_max<LPE>(s2), __builtin_fminf(m_curf, m_end));
+                    near_p = __ballot(tst <= p0f + paddf);
+                }
+                flagged = (__ballot(!(__builtin_fmaxf(e_curf, e_end) + dwf < w0f)) | near_p) != 0ull;
+                e_curf = e_end; m_curf = m_end;
+            } else {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    if (moving) {
+                        v.x = v.x + dta_d.x; v.y = v.y + dta_d.y;
+                        p.x = p.x + C.dt * v.x; p.y = p.y + C.dt * v.y;
+                    }
+                    float e, m;
+                    reaches(p, e, m);
+                    eacc = __builtin_fmaxf(eacc, e); macc = __builtin_fminf(macc, m);
+                }
+                flagged = (__ballot(!(eacc < w0f)) | __ballot(macc <= p0f)) != 0ull;
             }
             if (moving) acc = a;
-            if ((__ballot(!(eacc < w0f)) | __ballot(macc <= p0f)) != 0ull) {
+            if (flagged) {
                 // a flagged block (rare): its cycles again from the block's start, the same additions in the same order, each
                 // with its own decision (keeping the four positions and their distances in registers instead would cost the
                 // kernel its fourth wavefront per SIMD)
