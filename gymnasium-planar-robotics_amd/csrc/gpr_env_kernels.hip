@@ -987,7 +987,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
                     }
                     };
                     // (groups of up to 4 lanes: 4 movers x 65 536 envs -1.5 %; wider groups lose -- 8 movers +8 %, 16 movers +3 % -- three copies of their long sweeps)
-                    if constexpr (CHORD && LPE > 1 && LPE <= 4) {
+                    if constexpr (CHORD && LPE > 1 && LPE <= 4 && !MULTI) {  // (gpr_step_n: the copies cost it six spilled registers)
                         if (near_p == 0ull) examine(std::true_type{}, std::false_type{});
                         else if (near_w == 0ull) examine(std::false_type{}, std::true_type{});
                         else examine(std::true_type{}, std::true_type{});
