@@ -535,6 +535,9 @@ def main():
                             'max': head['rate_max'], 'region_seconds': head['region_seconds'], 'region_kernel_us': head['region_step_us']},
         'headline_attempts': head['attempts'],
         'done_fraction_per_step': head['done_fraction'], 'stream_probe': head['stream_probe'],
+        'thin_wavefronts': 'gpr_step launches of batches that leave SIMDs idle are spread over up to 1024 x {1, 2, 4} wavefronts (groups of <= 4 / 8 / 16 lanes '
+                           'per env; sub-batched handles share the budget) holding fewer envs each -- include/gpr.h: gpr_set_wave_budget; bit-identical results. '
+                           'It applies to the small shapes of config.baseline_configs / other_batch_sizes, not to the headline (4 096 wavefronts = 4 per SIMD)',
     }
     if backend:
         cfg['distributed'] = backend
