@@ -274,6 +274,7 @@ KParams make_params(gpr_env *e, const gpr_step_out *out, bool is_f64_ops) {
     P.counters = e->counters_on ? e->counters : nullptr;
     P.diag = e->diag; P.count_clipped = e->count_clipped ? 1 : 0;
     P.n_steps = 1;
+    P.thin_shift = thin_shift_for(e->cfg.num_envs, e->lpe, e->base.thin_waves);  // (step kernels; launch_kernel clears it for resets)
     if (out) {
         P.obs = out->observation_dev; P.ag = out->achieved_goal_dev; P.dg = out->desired_goal_dev; P.reward = out->reward_dev;
         P.terminated = out->terminated_dev; P.truncated = out->truncated_dev; P.is_success = out->is_success_dev;

@@ -111,6 +111,14 @@ __device__ __forceinline__ void warm_kernarg() {
                  : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3), "=&s"(w4), "=&s"(w5), "=&s"(w6), "=&s"(w7), "=&s"(w8), "=&s"(w9), "=&s"(w10), "=&s"(w11)
                  : "s"(kp) : "memory");
 }
+// thin wavefronts: log2 of "wavefront lanes / lanes that hold movers" for a launch of E envs in groups of lpe lanes under a budget of
+// `budget` wavefronts -- the largest spread that keeps whole env groups in a wavefront and the launch within the budget (0: whole wavefronts)
+inline int thin_shift_for(int64_t E, int lpe, int64_t budget) {
+    const int64_t natural = (E * lpe + 63) / 64;
+    int sh = 0;
+    while ((64 >> (sh + 1)) >= lpe && (natural << (sh + 1)) <= budget) ++sh;
+    return sh;
+}
 template <typename RT> __host__ __device__ __forceinline__ const Cst<RT> &cst(const KParams &P);
 template <> __host__ __device__ __forceinline__ const Cst<float> &cst<float>(const KParams &P) { return P.cf; }
 template <> __host__ __device__ __forceinline__ const Cst<double> &cst<double>(const KParams &P) { return P.cd; }

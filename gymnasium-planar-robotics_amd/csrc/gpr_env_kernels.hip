@@ -354,7 +354,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
     const int M = P.M;
-    // THIN WAVEFRONTS (P.thin_shift, wave-uniform; launch_kernel decides). What a wavefront's step costs beyond its quiet cycles are its
+    // THIN WAVEFRONTS (P.thin_shift, wave-uniform; make_params decides from the handle's wavefront budget). What a wavefront's step costs beyond its quiet cycles are its
     // EVENTS -- flagged blocks, cycles on the exact path, clamp-form blocks, resets served -- and their number grows with the envs the
     // wavefront holds, while a batch that leaves most SIMDs idle pays for the slowest wavefront only. So a small batch is spread over more
     // wavefronts: only the first 64 >> thin_shift lanes of a wavefront hold movers (the others are dead lanes, as in a batch's last
@@ -1739,14 +1739,10 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     } else if constexpr (GPR_ENV_PART == 1 && !WIDE) {
         return hipErrorInvalidValue;                                  // (nor this one in the other)
     } else {
-    // thin wavefronts (step_body): a batch that leaves SIMDs idle is spread over up to P.thin_waves wavefronts (gpr_api.hip: the handle's
-    // wavefront budget; 0 = never), each holding 64 >> thin_shift lanes of movers. gpr_step only: a gpr_step_n launch keeps whole wavefronts
+    // thin wavefronts (step_body): P.thin_shift comes from make_params (gpr_api.hip: the handle's wavefront budget) -- in the kernel
+    // argument for gpr_step, in every step's parameter block for gpr_step_n; resets keep whole wavefronts
     KParams Q = P;
-    Q.thin_shift = 0;
-    if (!is_reset && P.n_steps <= 1) {
-        const int64_t natural = (P.E * LPE + 63) / 64;
-        while ((64 >> (Q.thin_shift + 1)) >= LPE && (natural << (Q.thin_shift + 1)) <= (int64_t)P.thin_waves) ++Q.thin_shift;
-    }
+    if (is_reset) Q.thin_shift = 0;
     const int64_t live_per_block = (int64_t)(BLOCK / 64) * (64 >> Q.thin_shift);
     const int64_t threads = P.E * LPE;
     const unsigned grid = (unsigned)((threads + live_per_block - 1) / live_per_block);

@@ -143,7 +143,7 @@ int gpr_step_many(int32_t n, gpr_env *const *envs, const void *const *actions_de
  * three pairs of 150-us single-wavefront kernels and writes 1 (they overlapped) or 0; both streams are synchronised. */
 int gpr_streams_overlap(void *hip_stream_a, void *hip_stream_b, int32_t *overlap_out);
 
-/* Thin wavefronts: a gpr_step launch whose batch would leave SIMDs idle is spread over more wavefronts, each holding fewer envs (what a
+/* Thin wavefronts: a gpr_step / gpr_step_n launch whose batch would leave SIMDs idle is spread over more wavefronts, each holding fewer envs (what a
  * wavefront's step costs beyond its 40 quiet cycles -- flagged blocks, clamp-form blocks, resets served -- grows with the envs it holds,
  * and a small batch lasts as long as its slowest wavefront). Results do not depend on it: every random stream is keyed by global env id.
  * max_wavefronts = the most wavefronts one launch of this handle may be spread over; 0 turns it off; negative restores the default

@@ -709,6 +709,14 @@ def test_thin_wavefronts_equal_whole_wavefronts(gpr, M, n, E, kw):
                 assert torch.equal(res[0][4][k], r[4][k]), (t, k)
         n_done += int((res[0][2] | res[0][3]).sum())
     assert n_done > E // 2
+    # gpr_step_n under the same budgets (its steps' parameter blocks carry the spread): 12 more steps in one launch each
+    acts = (torch.rand(12, E, 2 * M, device='cuda', generator=g) * 20 - 10).to(envs[0].dtype)
+    rolls = [e.step_n(acts, e.alloc_rollout(12)) for e in envs]
+    for r in rolls[1:]:
+        for k in rolls[0]:
+            if isinstance(rolls[0][k], torch.Tensor):
+                assert torch.equal(rolls[0][k], r[k]), k
+    n_done += int((rolls[0]['terminated'].bool() | rolls[0]['truncated'].bool()).sum())
     tot = [e.read_episode_counters().cpu().numpy() for e in envs]
     for e in envs[1:]:
         assert torch.equal(envs[0].pos, e.pos) and torch.equal(envs[0].vel, e.vel) and torch.equal(envs[0].goals, e.goals)
