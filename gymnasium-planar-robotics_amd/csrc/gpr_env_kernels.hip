@@ -445,6 +445,14 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
         if (next_action != nullptr) carry->a_next = load2<ST, RT>(next_action, idx);  // consumed a whole step from now
         carry->c = c; carry->c1 = c1;
     }
+    // the lane's noise key (eight hash rounds, five of them on the scalar unit) depends on nothing that is loaded: formed HERE, while the
+    // loads are in flight (the compiler had put it behind their arrival), and pinned so that it stays here
+    // (float kernels of up to 8 lanes per env: -1 to -2 %; the 16-lane and the double kernels have no register to spare for it: +6 % / +1 %)
+    uint32_t key = 0u;
+    if constexpr (NOISE) {
+        key = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)mvc);
+        if constexpr (!Math<RT>::literal && LPE <= 8) asm volatile("" : "+v"(key));
+    }
     if (mv >= M) { p.x = p.y = far_away<RT>(); v.x = v.y = (RT)0; a.x = a.y = (RT)0; acc.x = acc.y = (RT)0; }  // group padding
     // the throughput-mode wall check of a full grid needs no table at all (pos_valid_circle): no LDS staging, no barrier
     if constexpr (!FULL || SHAPE == 1 || Math<RT>::literal) {  // (the box functions and the literal checks read the tables)
@@ -473,8 +481,6 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // per-env decisions are kept as wave masks (one bit per lane, identical within an env group): scalar registers
     unsigned long long frozen_m = __ballot(reset_first), wc_m = 0ull, mc_m = 0ull;
     const unsigned long long live_m = __ballot(live);
-    uint32_t key = 0u;
-    if constexpr (NOISE) key = rng_key(P, KIND_STEP_NOISE, env_global, (uint32_t)mvc);
 
     // Throughput (float) mode integrates DISPLACEMENTS: p = p0 + dp, v = v0 + dv with dp, dv summed from zero inside the
     // step (jerk mode never runs in float, see launch_flags). A constant velocity adds the same 1e-3-sized increment to a ~1 m position every cycle; summed
