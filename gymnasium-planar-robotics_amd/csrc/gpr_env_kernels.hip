@@ -349,7 +349,7 @@ __device__ __forceinline__ double lane_fetch(double v, int lane) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)(b >> 32));
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
-template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI>
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI, bool LONGBLK = false>
 __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarry<RT> *carry = nullptr, const void *next_action = nullptr) {
     extern __shared__ __align__(16) unsigned char lds[];
     const Cst<RT> &C = cst<RT>(P);
@@ -533,7 +533,10 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // cycles per block of the block loop below: 8 where the per-cycle trace of a block fits the registers (4 lanes per env,
     // circles: 127 of the 128 registers that keep 4 wavefronts per SIMD; one decision per 8 cycles: -2 % at 65 536 envs, -6 % at
     // 4 096), else 4 (8 lanes per env: +10 % with blocks of 8; layouts with holes, whose flagged blocks are replayed: +8 %)
-    constexpr int KB = (LPE <= 4 && SHAPE == 0 && FULL) ? 8 : 4;
+    // (LONGBLK: 8 lanes per env in THIN launches -- with the chord pre-test a block's cost is its one pair sweep, four ds_bpermute rotations
+    // there, and a thin launch has registers to spare: 8 192 x 8 movers 13.3 -> 12.6 us; at full occupancy the longer trace costs a
+    // wavefront per SIMD: 65 536 x 8 23.4 -> 24.6, so whole-wavefront launches keep blocks of 4)
+    constexpr int KB = ((LPE <= 4 || (LONGBLK && LPE == 8)) && SHAPE == 0 && FULL) ? 8 : 4;
     constexpr int KC1 = KB - 1, KC2 = 3 * KB - 1, KC3 = 39;  // rungs of the clamp ladder: 1 block, 3 blocks, 40 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
@@ -1675,6 +1678,15 @@ __global__ void __launch_bounds__(BLOCK, (SHAPE == 0 && FULL && LPE <= 4) ? ((Ma
 #endif
     step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false>(P, true);
 }
+// k_step for THIN launches of 8-lane groups: blocks of 8 cycles (step_body: LONGBLK). A kernel of its own name, so that k_step's stays what
+// the profiles of every round call it.
+template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE>
+__global__ void __launch_bounds__(BLOCK) k_step_thin(const KParams P) {
+#ifndef GPR_NO_WARM_KERNARG
+    warm_kernarg();
+#endif
+    step_body<ST, RT, LPE, JERK, NOISE, FULL, SHAPE, false, true>(P, true);
+}
 // gpr_step_n: n env-steps in ONE launch (actions and outputs [n][E][.]). Every wavefront walks through its envs' steps on its own:
 // no launch, no grid-wide drain and no simultaneous load burst of the whole batch between two steps, and no barrier either (a
 // wavefront resets its own envs). Step i reads its parameter block -- output rows i, call counter tick + i -- from steps[i] in
@@ -1769,6 +1781,12 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     } else if (P.n_steps > 1) {
         hipLaunchKernelGGL((k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P.step_params, P.n_steps);
     } else {
+        if constexpr (LPE == 8 && SHAPE == 0 && FULL && !Math<RT>::literal) {
+            if (Q.thin_shift > 0) {  // a thin launch of 8-lane groups: the variant with blocks of 8 cycles (step_body: LONGBLK)
+                hipLaunchKernelGGL((k_step_thin<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, Q);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((k_step<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, Q);
     }
     return hipGetLastError();
