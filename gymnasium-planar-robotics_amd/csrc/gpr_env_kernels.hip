@@ -349,6 +349,9 @@ __device__ __forceinline__ double lane_fetch(double v, int lane) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)(uint32_t)(b >> 32));
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+#ifndef GPR_THIN_KB
+#define GPR_THIN_KB 10
+#endif
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI, bool LONGBLK = false>
 __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarry<RT> *carry = nullptr, const void *next_action = nullptr) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -536,7 +539,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // (LONGBLK: 8 lanes per env in THIN launches -- with the chord pre-test a block's cost is its one pair sweep, four ds_bpermute rotations
     // there, and a thin launch has registers to spare: 8 192 x 8 movers 13.3 -> 12.6 us; at full occupancy the longer trace costs a
     // wavefront per SIMD: 65 536 x 8 23.4 -> 24.6, so whole-wavefront launches keep blocks of 4)
-    constexpr int KB = ((LPE <= 4 || (LONGBLK && LPE == 8)) && SHAPE == 0 && FULL) ? 8 : 4;
+    constexpr int KB = (SHAPE == 0 && FULL) ? ((LONGBLK && LPE <= 4) ? GPR_THIN_KB : (LPE <= 4 || (LONGBLK && LPE == 8)) ? 8 : 4) : 4;
     constexpr int KC1 = KB - 1, KC2 = 3 * KB - 1, KC3 = 39;  // rungs of the clamp ladder: 1 block, 3 blocks, 40 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
@@ -1781,7 +1784,7 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     } else if (P.n_steps > 1) {
         hipLaunchKernelGGL((k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P.step_params, P.n_steps);
     } else {
-        if constexpr (LPE == 8 && SHAPE == 0 && FULL && !Math<RT>::literal) {
+        if constexpr (LPE <= 8 && SHAPE == 0 && FULL && !Math<RT>::literal) {
             if (Q.thin_shift > 0) {  // a thin launch of 8-lane groups: the variant with blocks of 8 cycles (step_body: LONGBLK)
                 hipLaunchKernelGGL((k_step_thin<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, Q);
                 return hipGetLastError();
