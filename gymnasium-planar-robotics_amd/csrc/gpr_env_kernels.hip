@@ -352,6 +352,9 @@ __device__ __forceinline__ double lane_fetch(double v, int lane) {
 #ifndef GPR_THIN_KB
 #define GPR_THIN_KB 10
 #endif
+#ifndef GPR_THIN_KB8
+#define GPR_THIN_KB8 8
+#endif
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI, bool LONGBLK = false>
 __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarry<RT> *carry = nullptr, const void *next_action = nullptr) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -539,7 +542,7 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // (LONGBLK: 8 lanes per env in THIN launches -- with the chord pre-test a block's cost is its one pair sweep, four ds_bpermute rotations
     // there, and a thin launch has registers to spare: 8 192 x 8 movers 13.3 -> 12.6 us; at full occupancy the longer trace costs a
     // wavefront per SIMD: 65 536 x 8 23.4 -> 24.6, so whole-wavefront launches keep blocks of 4)
-    constexpr int KB = (SHAPE == 0 && FULL) ? ((LONGBLK && LPE <= 4) ? GPR_THIN_KB : (LPE <= 4 || (LONGBLK && LPE == 8)) ? 8 : 4) : 4;
+    constexpr int KB = (SHAPE == 0 && FULL) ? ((LONGBLK && LPE <= 4) ? GPR_THIN_KB : (LONGBLK && LPE == 8) ? GPR_THIN_KB8 : LPE <= 4 ? 8 : 4) : 4;
     constexpr int KC1 = KB - 1, KC2 = 3 * KB - 1, KC3 = 39;  // rungs of the clamp ladder: 1 block, 3 blocks, 40 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
