@@ -459,11 +459,15 @@ def roofline_of(r, precision, movers, tiles, envs=None, shape='circle'):
     kernel_us = r['step_us']
     achieved = S * B * epl / (kernel_us * 1e-6) / 1e9
     name = kernel_name(precision, movers, tiles, shape=shape)
-    if precision == 'f32' and shape == 'circle' and 4 < movers <= 8:
-        # thin launches of 8-lane groups run k_step_thin (blocks of 8 cycles): gpr_env_kernels.hip launch_kernel; the handle's wavefront
-        # budget is 2 048 for 8 lanes per env, shared by the sub-batches (VecBenchmarkPlanningEnvSubBatched)
-        budget = int(os.environ.get('GPR_THIN_WAVES', 2048 // S if S > 1 else 2048))
-        if 2 * ((epl * 8 + 63) // 64) <= budget:
+    if precision == 'f32' and shape == 'circle':
+        # thin launches run k_step_thin (longer blocks of cycles): gpr_env_kernels.hip launch_kernel; the handle's wavefront budget is
+        # 1 024 x {1, 2, 4} by lanes per env, shared by the sub-batches (VecBenchmarkPlanningEnvSubBatched)
+        lpe = 1
+        while lpe < movers:
+            lpe *= 2
+        full = 1024 * (4 if lpe >= 16 else 2 if lpe >= 8 else 1)
+        budget = int(os.environ.get('GPR_THIN_WAVES', full // S if S > 1 else full))
+        if 2 * lpe <= 64 and 2 * ((epl * lpe + 63) // 64) <= budget:
             name = name.replace('gpr::k_step<', 'gpr::k_step_thin<')
     tr = committed_profile('hbm_traffic', name, epl)
     frac = achieved / HBM_PEAK_GBS

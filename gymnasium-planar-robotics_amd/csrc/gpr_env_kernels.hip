@@ -355,6 +355,9 @@ __device__ __forceinline__ double lane_fetch(double v, int lane) {
 #ifndef GPR_THIN_KB8
 #define GPR_THIN_KB8 8
 #endif
+#ifndef GPR_THIN_KB16
+#define GPR_THIN_KB16 8
+#endif
 template <typename ST, typename RT, int LPE, bool JERK, bool NOISE, bool FULL, int SHAPE, bool MULTI, bool LONGBLK = false>
 __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarry<RT> *carry = nullptr, const void *next_action = nullptr) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -539,10 +542,12 @@ __device__ __forceinline__ void step_body(const KParams &P, bool first, StepCarr
     // cycles per block of the block loop below: 8 where the per-cycle trace of a block fits the registers (4 lanes per env,
     // circles: 127 of the 128 registers that keep 4 wavefronts per SIMD; one decision per 8 cycles: -2 % at 65 536 envs, -6 % at
     // 4 096), else 4 (8 lanes per env: +10 % with blocks of 8; layouts with holes, whose flagged blocks are replayed: +8 %)
-    // (LONGBLK: 8 lanes per env in THIN launches -- with the chord pre-test a block's cost is its one pair sweep, four ds_bpermute rotations
-    // there, and a thin launch has registers to spare: 8 192 x 8 movers 13.3 -> 12.6 us; at full occupancy the longer trace costs a
-    // wavefront per SIMD: 65 536 x 8 23.4 -> 24.6, so whole-wavefront launches keep blocks of 4)
-    constexpr int KB = (SHAPE == 0 && FULL) ? ((LONGBLK && LPE <= 4) ? GPR_THIN_KB : (LONGBLK && LPE == 8) ? GPR_THIN_KB8 : LPE <= 4 ? 8 : 4) : 4;
+    // (LONGBLK = THIN launches, k_step_thin: few envs per wavefront, so a block is rarely flagged and fewer, longer blocks pay -- and at one
+    // wavefront per SIMD the longer trace has the registers. Up to 4 lanes per env: 10 cycles (4 096 x 4 as one launch: blocks of 8 / 10 /
+    // 20: 8.92 / 8.53 / 8.83 us); 8 lanes: 8 cycles, one pair sweep -- four ds_bpermute rotations -- per 8 instead of per 4 cycles (8 192 x 8:
+    // 13.3 -> 12.6 us; blocks of 10 / 20: 12.8 / 13.9; at full occupancy the longer trace costs a wavefront per SIMD, 65 536 x 8: 23.4 ->
+    // 24.6, so whole-wavefront launches keep blocks of 4); 16 lanes: 8 cycles (4 096 x 16: 30.0 -> 28.7 us; 10: 28.9))
+    constexpr int KB = (SHAPE == 0 && FULL) ? ((LONGBLK && LPE <= 4) ? GPR_THIN_KB : (LONGBLK && LPE == 8) ? GPR_THIN_KB8 : (LONGBLK && LPE == 16) ? GPR_THIN_KB16 : LPE <= 4 ? 8 : 4) : 4;
     constexpr int KC1 = KB - 1, KC2 = 3 * KB - 1, KC3 = 39;  // rungs of the clamp ladder: 1 block, 3 blocks, 40 cycles
     const bool every = P.eager_noise != 0;
     const RT INF = Math<RT>::inf();
@@ -1787,7 +1792,7 @@ static hipError_t launch_kernel(bool is_reset, const KParams &P, hipStream_t s) 
     } else if (P.n_steps > 1) {
         hipLaunchKernelGGL((k_step_n<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, P.step_params, P.n_steps);
     } else {
-        if constexpr (LPE <= 8 && SHAPE == 0 && FULL && !Math<RT>::literal) {
+        if constexpr (SHAPE == 0 && FULL && !Math<RT>::literal) {
             if (Q.thin_shift > 0) {  // a thin launch of 8-lane groups: the variant with blocks of 8 cycles (step_body: LONGBLK)
                 hipLaunchKernelGGL((k_step_thin<ST, RT, LPE, JERK, NOISE, FULL, SHAPE>), dim3(grid), dim3(BLOCK), lds, s, Q);
                 return hipGetLastError();
