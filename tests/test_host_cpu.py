@@ -612,3 +612,39 @@ def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_oracle_golden.py'), '-x', '-q', '-p', 'no:cacheprovider'],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=280)
     assert r.returncode == 0 and ' passed' in r.stdout and 'Sanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_chord_pretest_bounds_hold_on_random_blocks():
+    """The inequalities behind the step kernels' chord pre-test (gpr_env_kernels.hip: chord_dw), on random blocks of cycles of the
+    semi-implicit Euler update with an acceleration bounded by A (adversarial: random, constant, sign-flipping): for every cycle k of a
+    block of K cycles (a) the wall reach max(|x|, |y| + kappa) stays below max(reach_0, reach_K) + A dt^2 K^2 / 8, and (b) the distance of
+    two movers stays above sqrt(min(|r_0|^2, |r_K|^2) - (s_i + s_j) / 2) - 2 A dt^2 K^2 / 8, s = a mover's squared displacement over
+    the block. (The kernels add the noise term to A and float slack to the bounds; the GPU tests hold the kernels themselves to
+    cycle-by-cycle evaluation bit for bit.)"""
+    rng = np.random.default_rng(11)
+    dt, A = 1e-3, np.sqrt(2.0) * 10.0
+    for K in (4, 8, 10, 20):
+        n = 40000
+        def block():
+            q = rng.uniform(-0.6, 0.6, (n, 2)); v = rng.uniform(-2.0, 2.0, (n, 2))
+            kind = rng.integers(0, 3, n)
+            base = rng.normal(size=(n, 2)); base *= (A * rng.uniform(0.0, 1.0, (n, 1))) / np.maximum(np.linalg.norm(base, axis=1, keepdims=True), 1e-30)
+            traj = [q.copy()]
+            for k in range(K):
+                a = np.where((kind == 0)[:, None], base, np.where((kind == 1)[:, None], base * (1 - 2 * (k % 2)), 0.0))
+                rnd = rng.normal(size=(n, 2)); rnd *= (A * rng.uniform(0.0, 1.0, (n, 1))) / np.maximum(np.linalg.norm(rnd, axis=1, keepdims=True), 1e-30)
+                a = np.where((kind == 2)[:, None], rnd, a)
+                v = v + dt * a
+                q = q + dt * v
+                traj.append(q.copy())
+            return np.stack(traj, axis=1)  # [n, K + 1, 2]
+        dw = A * dt * dt * K * K / 8.0
+        qi, qj = block(), block() + rng.uniform(-0.3, 0.3, (n, 1, 2))
+        kappa = 0.07
+        reach = np.maximum(np.abs(qi[..., 0]), np.abs(qi[..., 1]) + kappa)
+        assert np.all(reach.max(axis=1) <= np.maximum(reach[:, 0], reach[:, -1]) + dw + 1e-12)
+        r = qi - qj
+        d2 = (r ** 2).sum(-1)
+        s_i, s_j = ((qi[:, -1] - qi[:, 0]) ** 2).sum(-1), ((qj[:, -1] - qj[:, 0]) ** 2).sum(-1)
+        lower = np.sqrt(np.maximum(np.minimum(d2[:, 0], d2[:, -1]) - 0.5 * (s_i + s_j), 0.0)) - 2.0 * dw
+        assert np.all(np.sqrt(d2).min(axis=1) >= lower - 1e-12)
