@@ -468,7 +468,12 @@ def test_lazy_noise_is_exact(gpr, monkeypatch):
                                       (np.ones((6, 6)), 4, 'f32', box, 40),     # box shape on a grid without holes: fast wall / pair pre-tests
                                       (np.ones((6, 6)), 4, 'f32', None, 100),   # more cycles than an LDS row of readings holds
                                       (np.ones((8, 8)), 1, 'f32', None, 40),    # one mover: no pair check at all
-                                      (np.ones((10, 10)), 16, 'f32', None, 7)):  # 16 lanes per env, odd cycle count
+                                      (np.ones((10, 10)), 16, 'f32', None, 7),  # 16 lanes per env, odd cycle count
+                                      # cycle counts that are no multiple of a block (8 cycles, 10 in thin launches): the tail goes cycle by cycle;
+                                      # a negative count = the same with whole wavefronts (set_wave_budget(0)): the other block length
+                                      (np.ones((6, 6)), 4, 'f32', None, 37), (np.ones((6, 6)), 4, 'f32', None, -37),
+                                      (np.ones((8, 8)), 8, 'f32', None, 29), (np.ones((8, 8)), 8, 'f32', None, -29)):
+        whole, ncyc = ncyc < 0, abs(ncyc)
         E = 2048 if prec == 'f32' else 256
         kw = dict(num_envs=E, precision=prec, std_noise=np.array([2e-5, 1e-5, 0.0]), learn_jerk=(prec == 'f64'), collision_params=cp,
                   num_cycles=ncyc)
@@ -477,6 +482,8 @@ def test_lazy_noise_is_exact(gpr, monkeypatch):
         monkeypatch.setenv('GPR_EAGER_NOISE', '1')
         eager = gpr.VecBenchmarkPlanningEnv(layout, M, **kw)
         monkeypatch.delenv('GPR_EAGER_NOISE', raising=False)
+        if whole:
+            lazy.set_wave_budget(0); eager.set_wave_budget(0)
         lazy.reset(seed=11); eager.reset(seed=11)
         g = torch.Generator(device='cuda').manual_seed(5)
         lim = lazy.j_max if lazy.learn_jerk else lazy.a_max
