@@ -518,7 +518,7 @@ int gpr_create(const gpr_config *cfg, gpr_env **out_env) {
 #ifdef GPR_WAVE_TIMING
     // debug build: per-wavefront clocks of the last step kernel, dumped to $GPR_WAVE_TIMING (a file name) by gpr_destroy
     if (std::getenv("GPR_WAVE_TIMING")) {
-        e->wave_timing_words = (size_t)(std::max<int64_t>((c.num_envs * e->lpe + 63) / 64, (int64_t)P.thin_waves) + BLOCK / 64) * 16;
+        e->wave_timing_words = (size_t)(std::max<int64_t>((c.num_envs * e->lpe + 63) / 64, (int64_t)P.thin_waves) + 8) * 16;
         if (hipMalloc(&P.wave_timing, e->wave_timing_words * 4) == hipSuccess) (void)hipMemset(P.wave_timing, 0, e->wave_timing_words * 4);
         else P.wave_timing = nullptr;
     }
@@ -590,8 +590,8 @@ int gpr_enable_counters(gpr_env *env, int32_t enable) {
         // read and write their (zero) rows. Planning: lpe lanes per env; pushing: up to PUSH_LANES lanes per env (k_push).
         const int64_t lanes = env->push_ready ? std::max<int64_t>(env->lpe, PUSH_LANES) : env->lpe;
         // (a thin gpr_step launch has up to base.thin_waves wavefronts, rounded up to whole blocks)
-        const size_t rows = std::max((size_t)((env->cfg.num_envs * lanes + BLOCK - 1) / BLOCK) * (size_t)(BLOCK / 64),
-                                     (size_t)((env->base.thin_waves + BLOCK / 64 - 1) / (BLOCK / 64) + 1) * (size_t)(BLOCK / 64));
+        // (whole blocks of up to 512 threads: the widest block any step kernel is built with)
+        const size_t rows = std::max((size_t)((env->cfg.num_envs * lanes + 511) / 512) * 8u, (size_t)env->base.thin_waves + 8u);
         if (env->counters && rows > env->counter_rows) {  // (gpr_push_configure came after the table was made: a larger one, counts restart)
             (void)hipDeviceSynchronize();
             (void)hipFree(env->counters);
@@ -613,10 +613,10 @@ int gpr_enable_counters(gpr_env *env, int32_t enable) {
 int gpr_set_wave_budget(gpr_env *env, int32_t max_wavefronts) {
     if (!env) return fail(nullptr, GPR_E_INVALID, "gpr_set_wave_budget: NULL handle");
     const int32_t w = max_wavefronts < 0 ? default_wave_budget(env->lpe) : (max_wavefronts > 65536 ? 65536 : max_wavefronts);
-    if (env->counters && (size_t)w + BLOCK / 64 > env->counter_rows)  // (a launch's grid: the budget rounded up to whole blocks)
+    if (env->counters && (size_t)w + 8u > env->counter_rows)  // (a launch's grid: the budget rounded up to whole blocks of up to 8 wavefronts)
         return fail(env, GPR_E_INVALID, "gpr_set_wave_budget: the counter table was made for fewer wavefronts (set the budget before gpr_enable_counters)");
 #ifdef GPR_WAVE_TIMING
-    if (env->base.wave_timing && (size_t)(w + BLOCK / 64) * 16 > env->wave_timing_words) return fail(env, GPR_E_INVALID, "gpr_set_wave_budget: beyond the timing table");
+    if (env->base.wave_timing && (size_t)(w + 8) * 16 > env->wave_timing_words) return fail(env, GPR_E_INVALID, "gpr_set_wave_budget: beyond the timing table");
 #endif
     env->base.thin_waves = w;
     return GPR_OK;
